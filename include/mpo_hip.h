@@ -1,0 +1,84 @@
+/* libmpo_hip.so -- C ABI of the MI355X (gfx950) WSI-patch x omics fusion kernels.
+ *
+ * The reference (mattiagualtieri/multimodal-path-omic) is pure Python on stock PyTorch and has no
+ * FFI of its own; its seam is the nn.Module attribute slots of the two models
+ * (models/mcat/mcat.py:48-82, models/nacagat/nacagat.py:44-78).  Each entry point below replaces the
+ * arithmetic behind one of those slots and is what a binding for that slot would call
+ * (INTEGRATION.md shows the ctypes stubs).  Conventions, all entries:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch allocates inputs, outputs, saved tensors and workspaces; the library allocates nothing
+ *     persistent and keeps no pointer after returning);
+ *   - asynchronous on the hipStream_t passed last; re-entrant; no global mutable state except the
+ *     thread-local last-error string;
+ *   - returns 0 on success, non-zero on error (never throws); mpo_last_error() describes it;
+ *   - row-major fp32 unless a dtype argument says otherwise; "bag" tensors may be fp32 or bf16
+ *     (MPO_F32 / MPO_BF16): bf16 is a STORAGE format, accumulation is always fp32;
+ *   - a window of n_slides slides is processed per call.  Bags are concatenated along rows
+ *     ("ragged"): slide b owns rows cu_rows[b] .. cu_rows[b+1]-1 of the bag; cu_rows is a DEVICE
+ *     int32 array of n_slides+1 entries; max_rows = longest bag and total_rows = cu_rows[n_slides]
+ *     are passed from the host for grid sizing.  n_slides = 1 is the reference's per-slide call.
+ *   - attention maps are ragged too: slide b's (n_q, M_b) block starts at float offset
+ *     n_q * cu_rows[b], row stride M_b.
+ */
+#ifndef MPO_HIP_H
+#define MPO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mpo_stream_t;   /* == hipStream_t */
+
+enum { MPO_F32 = 0, MPO_BF16 = 1 };
+enum { MPO_ACT_NONE_ = 0, MPO_ACT_RELU_ = 1, MPO_ACT_ELU_ = 2, MPO_ACT_TANH_ = 3, MPO_ACT_SIGMOID_ = 4 };
+
+int mpo_abi_version(void);
+const char* mpo_last_error(void);
+
+/* ---- building block: y = act(alpha * (x W^T + b)) and its two backward products, on the fp32 MFMA.
+ * Stands in for torch.nn.functional.linear on the 6 x 256-token tail. */
+int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y,
+                       int rows, int in_features, int out_features, float alpha, int act, mpo_stream_t stream);
+int mpo_linear_backward_input(const float* dy, const float* weight, float* dx,
+                              int rows, int in_features, int out_features, float alpha, int accumulate,
+                              mpo_stream_t stream);
+int mpo_linear_backward_weight(const float* dy, const float* x, float* dweight, float* dbias /* nullable */,
+                               int rows, int in_features, int out_features, float alpha, mpo_stream_t stream);
+
+/* ---- K1: MCAT genomic-guided co-attention = nn.MultiheadAttention(embed, num_heads=1)(query, bag, bag)
+ * Replaces models/mcat/mcat.py:48 (constructor) / :97 (call); arithmetic of
+ * torch/nn/functional.py:6206-6660 (packed in-projection, 1/sqrt(E) scaling, softmax, out_proj).
+ *   query        [n_slides*n_q, embed] fp32        in_proj_weight [3*embed, embed], in_proj_bias [3*embed]
+ *   out          [n_slides*n_q, embed] fp32        out_proj_weight [embed, embed],  out_proj_bias [embed]
+ *   attn_map     NULL (need_weights=False) or ragged fp32 map (need_weights=True)
+ *   saved        mpo_coattn_saved_floats() floats kept for the backward call
+ */
+size_t mpo_coattn_saved_floats(int n_slides, int n_q, int embed);
+size_t mpo_coattn_workspace_bytes(int n_slides, int n_q, int embed, int max_rows);
+int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides,
+                            int total_rows, int max_rows,
+                            const float* query, int n_q, int embed,
+                            const float* in_proj_weight, const float* in_proj_bias,
+                            const float* out_proj_weight, const float* out_proj_bias,
+                            float* out, float* attn_map, float* saved,
+                            void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+/* d_attn_map (nullable): gradient arriving on the returned map; needs attn_map from the forward.
+ * d_bag has the bag's dtype.  d_in_proj_bias[embed..2*embed) (the key bias) is exactly zero: a key
+ * bias shifts every logit of a row equally and cancels in the softmax. */
+int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides,
+                             int total_rows, int max_rows,
+                             const float* query, int n_q, int embed,
+                             const float* in_proj_weight, const float* out_proj_weight,
+                             const float* saved, const float* attn_map,
+                             const float* d_out, const float* d_attn_map,
+                             float* d_query, void* d_bag,
+                             float* d_in_proj_weight, float* d_in_proj_bias,
+                             float* d_out_proj_weight, float* d_out_proj_bias,
+                             void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPO_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libmpo_hip.so (C ABI: include/mpo_hip.h).
+
+There is deliberately no fallback: if the shared library is missing, or a call returns
+non-zero, a RuntimeError is raised.  Tensors cross the boundary as raw device pointers
+(`tensor.data_ptr()`), sizes, and the current HIP stream of the tensor's device.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpo_hip.so")
+
+MPO_F32, MPO_BF16 = 0, 1
+ACT = {"none": 0, "relu": 1, "elu": 2, "tanh": 3, "sigmoid": 4}
+
+_lib = None
+
+_P = c_void_p
+_SIGNATURES = {
+    "mpo_abi_version": (c_int, []),
+    "mpo_last_error": (c_char_p, []),
+    "mpo_linear_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
+    "mpo_linear_backward_input": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
+    "mpo_linear_backward_weight": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "mpo_coattn_saved_floats": (c_size_t, [c_int, c_int, c_int]),
+    "mpo_coattn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mpo_coattn_mcat_forward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
+                                        _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
+                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+}
+
+
+def exported_symbols():
+    """Names every build of the library must export (checked by the CPU test-suite)."""
+    return list(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().mpo_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libmpo_hip operates on GPU tensors only (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("libmpo_hip needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def bag_dtype_code(t):
+    if t.dtype == torch.float32:
+        return MPO_F32
+    if t.dtype == torch.bfloat16:
+        return MPO_BF16
+    raise RuntimeError(f"bag dtype must be float32 or bfloat16, got {t.dtype}")

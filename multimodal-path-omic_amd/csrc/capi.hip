@@ -1,0 +1,182 @@
+// extern "C" entry points of libmpo_hip.so (declared in include/mpo_hip.h) and the host-side
+// orchestration of each one: a fixed sequence of kernel launches on the caller's stream, working
+// only in caller-provided buffers.  No allocation, no synchronisation, graph-capturable.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/mpo_hip.h"
+#include "mpo_common.h"
+#include "mpo_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void mpo_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Arena {
+    char* base;
+    size_t size, off = 0;
+    Arena(void* p, size_t n) : base(static_cast<char*>(p)), size(n) {}
+    float* floats(size_t n) {
+        const size_t o = align_up(off, 256);
+        if (o + n * 4 > size) return nullptr;
+        off = o + n * 4;
+        return reinterpret_cast<float*>(base + o);
+    }
+};
+static inline size_t arena_need(size_t acc, size_t n_floats) { return align_up(acc, 256) + n_floats * 4; }
+
+int mpo_coattn_splits(int n_slides, int max_rows) {
+    // ~4 workgroups per CU over the window; at least one 32-row tile per wave of a workgroup
+    int s = (1024 + n_slides - 1) / n_slides;
+    const int cap = (max_rows + 127) / 128;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" {
+
+int mpo_abi_version(void) { return 1; }
+const char* mpo_last_error(void) { return g_err; }
+
+int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
+                       int out_features, float alpha, int act, mpo_stream_t stream) {
+    return mpo_linear_fwd(x, weight, bias, y, rows, in_features, out_features, alpha, act, stream);
+}
+int mpo_linear_backward_input(const float* dy, const float* weight, float* dx, int rows, int in_features,
+                              int out_features, float alpha, int accumulate, mpo_stream_t stream) {
+    return mpo_linear_bwd_input(dy, weight, dx, rows, in_features, out_features, alpha, accumulate, stream);
+}
+int mpo_linear_backward_weight(const float* dy, const float* x, float* dweight, float* dbias, int rows,
+                               int in_features, int out_features, float alpha, mpo_stream_t stream) {
+    return mpo_linear_bwd_weight(dy, x, dweight, dbias, rows, in_features, out_features, alpha, stream);
+}
+
+// ------------------------------------------------------------------------------------------- K1
+// saved layout (floats), R = n_slides * n_q:   qs [R,E] | qk2 [R,E] | ctx [R,E] | attn [R,E] | lse2 [R]
+size_t mpo_coattn_saved_floats(int n_slides, int n_q, int embed) {
+    const size_t R = (size_t)n_slides * n_q;
+    return 4 * R * embed + R;
+}
+
+size_t mpo_coattn_workspace_bytes(int n_slides, int n_q, int embed, int max_rows) {
+    const size_t R = (size_t)n_slides * n_q;
+    const size_t splits = mpo_coattn_splits(n_slides, max_rows);
+    size_t a = 0;
+    // forward: part_ml, part_ctx.  backward: dattn, dctx, dqk, dq_pre, delta, part_dqk  (take the larger)
+    size_t f = 0;
+    f = arena_need(f, (size_t)n_slides * splits * 32);
+    f = arena_need(f, (size_t)n_slides * splits * n_q * embed);
+    size_t b = 0;
+    for (int i = 0; i < 4; ++i) b = arena_need(b, R * embed);
+    b = arena_need(b, R);
+    b = arena_need(b, (size_t)n_slides * splits * n_q * embed);
+    a = f > b ? f : b;
+    return a + 256;
+}
+
+static int check_common(int bag_dtype, int n_slides, int total_rows, int max_rows, int n_q, int embed) {
+    MPO_CHECK(bag_dtype == MPO_F32 || bag_dtype == MPO_BF16, "bag dtype %d is neither MPO_F32 nor MPO_BF16", bag_dtype);
+    MPO_CHECK(n_slides >= 1, "n_slides must be >= 1 (got %d)", n_slides);
+    MPO_CHECK(n_q >= 1 && n_q <= 16, "number of omic queries must be in 1..16 (got %d)", n_q);
+    MPO_CHECK(embed == 128 || embed == 256 || embed == 512, "embed_dim %d not in {128,256,512}", embed);
+    MPO_CHECK(max_rows >= 1 && total_rows >= n_slides, "every slide needs at least one patch (total_rows %d, max_rows %d)",
+              total_rows, max_rows);
+    return 0;
+}
+
+int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int total_rows,
+                            int max_rows, const float* query, int n_q, int embed, const float* in_w,
+                            const float* in_b, const float* out_w, const float* out_b, float* out, float* attn_map,
+                            float* saved, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
+    const int E = embed, R = n_slides * n_q;
+    const int splits = mpo_coattn_splits(n_slides, max_rows);
+    Arena ws(workspace, workspace_bytes);
+    float* part_ml = ws.floats((size_t)n_slides * splits * 32);
+    float* part_ctx = ws.floats((size_t)n_slides * splits * n_q * E);
+    MPO_CHECK(part_ml && part_ctx, "coattn forward: workspace too small (%zu bytes)", workspace_bytes);
+    float* qs = saved;
+    float* qk2 = qs + (size_t)R * E;
+    float* ctx = qk2 + (size_t)R * E;
+    float* attn = ctx + (size_t)R * E;
+    float* lse2 = attn + (size_t)R * E;
+    const float scale = 1.0f / sqrtf((float)E);
+    int rc;
+    // qs = (query W_q^T + b_q) / sqrt(E)
+    if ((rc = mpo_linear_fwd(query, in_w, in_b, qs, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
+    // qk2 = log2(e) * qs W_k     (fold of the key projection into the query; key bias cancels in softmax)
+    if ((rc = mpo_linear_bwd_input(qs, in_w + (size_t)E * E, qk2, R, E, E, kLog2e, 0, stream))) return rc;
+    if ((rc = mpo_launch_coattn_fwd_partial(bag, bag_dtype == MPO_F32, cu_rows, n_slides, E, qk2, part_ml, part_ctx,
+                                            attn_map, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_coattn_combine(part_ml, part_ctx, ctx, lse2, n_slides, n_q, E, splits, stream))) return rc;
+    // attn = ctx W_v^T + b_v   (rows of A sum to one);  out = attn W_o^T + b_o
+    if ((rc = mpo_linear_fwd(ctx, in_w + (size_t)2 * E * E, in_b + 2 * E, attn, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
+    if ((rc = mpo_linear_fwd(attn, out_w, out_b, out, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
+    if (attn_map)
+        if ((rc = mpo_launch_coattn_normalize(attn_map, lse2, cu_rows, n_slides, n_q, max_rows, 0.f, 0, 0, stream))) return rc;
+    return 0;
+}
+
+int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int total_rows,
+                             int max_rows, const float* query, int n_q, int embed, const float* in_w,
+                             const float* out_w, const float* saved, const float* attn_map, const float* d_out,
+                             const float* d_attn_map, float* d_query, void* d_bag, float* d_in_w, float* d_in_b,
+                             float* d_out_w, float* d_out_b, void* workspace, size_t workspace_bytes,
+                             mpo_stream_t stream) {
+    if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
+    MPO_CHECK(embed != 512, "coattn backward: embed_dim 512 ('big') is not built yet");
+    MPO_CHECK(!d_attn_map || attn_map, "coattn backward: a gradient on the attention map needs the forward's map");
+    const int E = embed, R = n_slides * n_q;
+    const int splits = mpo_coattn_splits(n_slides, max_rows);
+    Arena ws(workspace, workspace_bytes);
+    float* dattn = ws.floats((size_t)R * E);
+    float* dctx = ws.floats((size_t)R * E);
+    float* dqk = ws.floats((size_t)R * E);
+    float* dq_pre = ws.floats((size_t)R * E);
+    float* delta = ws.floats(R);
+    float* part_dqk = ws.floats((size_t)n_slides * splits * n_q * E);
+    MPO_CHECK(dattn && dctx && dqk && dq_pre && delta && part_dqk, "coattn backward: workspace too small (%zu bytes)", workspace_bytes);
+    const float* qs = saved;
+    const float* qk2 = qs + (size_t)R * E;
+    const float* ctx = qk2 + (size_t)R * E;
+    const float* attn = ctx + (size_t)R * E;
+    const float* lse2 = attn + (size_t)R * E;
+    const float* w_q = in_w;
+    const float* w_k = in_w + (size_t)E * E;
+    const float* w_v = in_w + (size_t)2 * E * E;
+    const float scale = 1.0f / sqrtf((float)E);
+    int rc;
+    // out = attn W_o^T + b_o
+    if ((rc = mpo_linear_bwd_input(d_out, out_w, dattn, R, E, E, 1.0f, 0, stream))) return rc;
+    if ((rc = mpo_linear_bwd_weight(d_out, attn, d_out_w, d_out_b, R, E, E, 1.0f, stream))) return rc;
+    // attn = ctx W_v^T + b_v
+    if ((rc = mpo_linear_bwd_input(dattn, w_v, dctx, R, E, E, 1.0f, 0, stream))) return rc;
+    if ((rc = mpo_linear_bwd_weight(dattn, ctx, d_in_w + (size_t)2 * E * E, d_in_b + 2 * E, R, E, E, 1.0f, stream))) return rc;
+    // delta = rowsum(dctx * ctx) [+ rowsum(A * dA_ext)]
+    if ((rc = mpo_launch_rowdot(dctx, ctx, delta, R, E, stream))) return rc;
+    if (d_attn_map)
+        if ((rc = mpo_launch_map_rowdot(attn_map, d_attn_map, cu_rows, delta, n_slides, n_q, 1, stream))) return rc;
+    // the bag pass
+    if ((rc = mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, E, qk2, lse2, dctx, delta, attn_map,
+                                    d_attn_map, d_bag, part_dqk, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_coattn_bwd_reduce(part_dqk, dqk, n_slides, n_q, E, splits, stream))) return rc;
+    // qk = qs W_k :  dqs = dqk W_k^T (folded with the 1/sqrt(E) of qs = scale * (...)),  dW_k = qs^T dqk,  db_k = 0
+    if ((rc = mpo_linear_fwd(dqk, w_k, nullptr, dq_pre, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
+    if ((rc = mpo_linear_bwd_weight(qs, dqk, d_in_w + (size_t)E * E, nullptr, R, E, E, 1.0f, stream))) return rc;
+    MPO_HIP(hipMemsetAsync(d_in_b + E, 0, (size_t)E * sizeof(float), stream));
+    // q_pre = query W_q^T + b_q
+    if ((rc = mpo_linear_bwd_input(dq_pre, w_q, d_query, R, E, E, 1.0f, 0, stream))) return rc;
+    if ((rc = mpo_linear_bwd_weight(dq_pre, query, d_in_w, d_in_b, R, E, E, 1.0f, stream))) return rc;
+    return 0;
+}
+
+}  // extern "C"

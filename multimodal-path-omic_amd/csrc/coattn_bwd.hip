@@ -1,0 +1,347 @@
+// K1 backward: one pass over the bag recomputes the folded co-attention from the saved
+// log-sum-exp and emits  dH (gradient of the bag, written once, coalesced)  and split-M
+// partials of  dqk (gradient of the folded query qk = (q/sqrt(E)) W_k).
+//
+// With  S[n][m] = qk[n].H[m],  A = softmax(S),  ctx = A H  (coattn_fwd.hip) and upstream
+// gradients dctx (N x E) and, optionally, dA_ext on the attention map itself (the NaCAGaT
+// 'cesar' loss back-propagates into the map: models/loss.py:97, models/nacagat/main.py:49-50):
+//   dA[n][m]  = dctx[n].H[m] + dA_ext[n][m]
+//   dS[n][m]  = A[n][m] (dA[n][m] - delta[n]),   delta[n] = dctx[n].ctx[n] + sum_m A dA_ext
+//   dqk[n]    = sum_m dS[n][m] H[m]
+//   dH[m]     = sum_n A[n][m] dctx[n] + dS[n][m] qk[n]
+// Per 32-row tile the MFMA runs the two row products (scores, dA) in BOTH orientations -- query
+// on the lane for the dqk accumulation (as the forward), patch on the lane for dH -- by swapping
+// the operand roles of the same registers; nothing is transposed through memory.  dH is formed
+// as  dH^T[d][p] = Z^T[d][k] W^T[k][p]  with k running over (A rows | dS rows), so each lane owns
+// 4 consecutive d of one patch; the tile's own LDS image is overwritten with dH and copied out
+// in whole rows.
+#include "coattn_tile.h"
+#include "mpo_kernels.h"
+
+namespace {
+
+template <int E_, bool F32BAG>
+struct BwdCfg {
+    static constexpr int NT = F32BAG ? 2 : 1;
+    static constexpr int WAVES = (F32BAG && E_ == 512) ? 2 : 4;
+    static constexpr int WAVE_LDS = NT * TileGeom<E_>::TILEB;     // also holds the dH image (E*2*32 or E*4*32 bytes)
+    static constexpr int LDS_BYTES = WAVES * WAVE_LDS;
+};
+
+// rows-on-lane orientation: out[pt][r] = sum_k x[4g + r][k] * tile[16pt + (lane&15)][k]
+template <int E_, int NT>
+__device__ __forceinline__ void tile_dot_rows_T(const char* thi, const char* tlo,
+                                                const bf16x8 (&xh)[TileGeom<E_>::KS], const bf16x8 (&xl)[TileGeom<E_>::KS],
+                                                f32x4& s0, f32x4& s1, int lane) {
+#pragma unroll
+    for (int s = 0; s < TileGeom<E_>::KS; ++s) {
+        const bf16x8 a0 = row_frag<E_>(thi, 0, s, lane);
+        const bf16x8 a1 = row_frag<E_>(thi, 1, s, lane);
+        s0 = mfma_bf16(xh[s], a0, s0);
+        s1 = mfma_bf16(xh[s], a1, s1);
+        s0 = mfma_bf16(xl[s], a0, s0);
+        s1 = mfma_bf16(xl[s], a1, s1);
+        if (NT == 2) {
+            const bf16x8 b0 = row_frag<E_>(tlo, 0, s, lane);
+            const bf16x8 b1 = row_frag<E_>(tlo, 1, s, lane);
+            s0 = mfma_bf16(xh[s], b0, s0);
+            s1 = mfma_bf16(xh[s], b1, s1);
+        }
+    }
+}
+
+template <int E_, bool F32BAG>
+__global__ __launch_bounds__((BwdCfg<E_, F32BAG>::WAVES * 64), 1)
+void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu,
+                       const float* __restrict__ qk2,      // [n_slides][n_q][E] log2 units
+                       const float* __restrict__ lse2,     // [n_slides][n_q]    log2 units
+                       const float* __restrict__ dctx,     // [n_slides][n_q][E]
+                       const float* __restrict__ delta,    // [n_slides][n_q]
+                       const float* __restrict__ da_map,   // nullable, ragged [n_q][M_b] per slide
+                       void* __restrict__ dbag_,           // [total_rows][E], bag dtype
+                       float* __restrict__ part_dqk,       // [n_slides][splits][n_q][E] (natural units)
+                       int n_q, int splits) {
+    using G = TileGeom<E_>;
+    using C = BwdCfg<E_, F32BAG>;
+    constexpr int WAVES = C::WAVES;
+    constexpr int NT = C::NT;
+    constexpr int EB = F32BAG ? 4 : 2;                            // bytes per bag element
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
+    const int rps = ((m_rows + splits - 1) / splits + kTileRows - 1) / kTileRows * kTileRows;
+    const int r0 = split * rps;
+    const int r1 = min(m_rows, r0 + rps);
+    const int ntiles = r1 > r0 ? (r1 - r0 + kTileRows - 1) / kTileRows : 0;
+    const int n_my = wave < ntiles ? (ntiles - wave + WAVES - 1) / WAVES : 0;
+
+    char* thi = lds + wave * C::WAVE_LDS;
+    char* tlo = thi + (NT - 1) * G::TILEB;
+    const int c16 = lane & 15, g = lane >> 4;
+    const float* qk_b = qk2 + (size_t)b * n_q * E_;
+    const float* dc_b = dctx + (size_t)b * n_q * E_;
+
+    // operands indexed by the query (hi/lo): used as MFMA B (query on lane) and as MFMA A (patch on lane)
+    bf16x8 qh[G::KS], ql[G::KS], dch[G::KS], dcl[G::KS];
+    load_query_frags<E_>(qk_b, n_q, lane, qh, ql);
+    load_query_frags<E_>(dc_b, n_q, lane, dch, dcl);
+
+    // Z^T operand of the dH product, per 16-column tile t: lane (d = 16t + c16, g) element j:
+    //   j < 4 : dctx[4g + j][d]          j >= 4 : qk_nat[4g + j - 4][d]      (zero for query rows >= n_q)
+    bf16x8 zh[G::DT];
+    bf16x8 zl[NT == 2 ? G::DT : 1];
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) {
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qq = 4 * g + j;
+            const int qc = qq < n_q ? qq : n_q - 1;
+            const float live = qq < n_q ? 1.0f : 0.0f;
+            z[j] = dc_b[qc * E_ + 16 * t + c16] * live;
+            z[4 + j] = qk_b[qc * E_ + 16 * t + c16] * (live * kLn2);
+        }
+        bf16x8 h, l;
+        pack_hi_lo(z, h, l);
+        zh[t] = h;
+        if (NT == 2) zl[t] = l;
+    }
+
+    // per-lane row constants in both orientations; +inf lse switches padded query rows off (A = 0)
+    const float lse_q = c16 < n_q ? lse2[(size_t)b * n_q + c16] : INFINITY;
+    const float del_q = c16 < n_q ? delta[(size_t)b * n_q + c16] : 0.f;
+    float lse_p[4], del_p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qq = 4 * g + r;
+        lse_p[r] = qq < n_q ? lse2[(size_t)b * n_q + qq] : INFINITY;
+        del_p[r] = qq < n_q ? delta[(size_t)b * n_q + qq] : 0.f;
+    }
+    const float* da_b = da_map ? da_map + (size_t)n_q * row_begin : nullptr;
+
+    f32x4 accq[G::DT];
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) accq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* slide = reinterpret_cast<const char*>(bag_) + (size_t)row_begin * E_ * EB;
+    char* dslide = reinterpret_cast<char*>(dbag_) + (size_t)row_begin * E_ * EB;
+
+    Stage<E_, F32BAG> st0;
+    Stage<E_, F32BAG> st1;
+    if (n_my > 0) {
+        st0.load(slide, r0 + kTileRows * wave, m_rows, 0, lane);
+        if constexpr (F32BAG) st1.load(slide, r0 + kTileRows * wave, m_rows, 1, lane);
+    }
+    for (int it = 0; it < n_my; ++it) {
+        const int trow = r0 + kTileRows * (wave + it * WAVES);
+        const int nvalid = min(kTileRows, r1 - trow);
+        st0.store(thi, tlo, 0, lane);
+        if constexpr (F32BAG) st1.store(thi, tlo, 1, lane);
+        if (it + 1 < n_my) {
+            st0.load(slide, trow + kTileRows * WAVES, m_rows, 0, lane);
+            if constexpr (F32BAG) st1.load(slide, trow + kTileRows * WAVES, m_rows, 1, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------------- query on the lane: dS^T -> dqk accumulation
+        {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+            tile_dot_rows<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
+            tile_dot_rows<E_, NT>(thi, tlo, dch, dcl, d0, d1, lane);
+            float ds[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int row = 16 * pt + 4 * g + r;
+                    const bool ok = row < nvalid;
+                    float da = pt == 0 ? d0[r] : d1[r];
+                    if (da_b != nullptr && ok && c16 < n_q) da += da_b[(size_t)c16 * m_rows + trow + row];
+                    const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_q) : 0.f;
+                    ds[4 * pt + r] = a * (da - del_q);
+                }
+            }
+            bf16x8 wh, wl;
+            pack_hi_lo(ds, wh, wl);
+            tile_accum_cols<E_, NT>(thi, tlo, wh, wl, accq, lane);
+        }
+
+        // ---------------- patch on the lane: A, dS with the query index in the registers
+        bf16x8 wph[2], wpl[2];
+        {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+            tile_dot_rows_T<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
+            tile_dot_rows_T<E_, NT>(thi, tlo, dch, dcl, d0, d1, lane);
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int row = 16 * pt + c16;
+                const bool ok = row < nvalid;
+                float w[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = 4 * g + r;
+                    float da = pt == 0 ? d0[r] : d1[r];
+                    if (da_b != nullptr && ok && qq < n_q) da += da_b[(size_t)qq * m_rows + trow + row];
+                    const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_p[r]) : 0.f;
+                    w[r] = a;
+                    w[4 + r] = a * (da - del_p[r]);
+                }
+                pack_hi_lo(w, wph[pt], wpl[pt]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------------- dH^T[d][p] = Z^T W^T, written over the (now dead) tile image
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int row = 16 * pt + c16;
+#pragma unroll
+            for (int t = 0; t < G::DT; ++t) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                o = mfma_bf16(zh[t], wph[pt], o);
+                if (NT == 2) {
+                    o = mfma_bf16(zh[t], wpl[pt], o);
+                    o = mfma_bf16(zl[t], wph[pt], o);
+                }
+                // lane holds dH[row][16t + 4g .. +3]
+                if constexpr (!F32BAG) {
+                    bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    const int c = (2 * t + (g >> 1)) ^ ((row & 7) << 1);
+                    *reinterpret_cast<bf16x4*>(thi + row * G::ROWB + (c << 4) + 8 * (g & 1)) = ob;
+                } else {
+                    const int c = (4 * t + g) ^ ((row & 7) << 1);
+                    *reinterpret_cast<f32x4*>(thi + row * (E_ * 4) + (c << 4)) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------------- copy the dH image out in whole rows (1 KiB per wave-instruction)
+        {
+            constexpr int CH_PER_ROW = E_ * EB / 16;
+            constexpr int NCH = kTileRows * CH_PER_ROW / 64;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ci = i * 64 + lane;
+                const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(thi + r * (E_ * EB) + ((cc ^ ((r & 7) << 1)) << 4));
+                if (r < nvalid)
+                    *reinterpret_cast<f32x4*>(dslide + ((size_t)(trow + r) * CH_PER_ROW + cc) * 16) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- merge the waves' dqk through LDS and write this workgroup's partial
+    __syncthreads();
+    {
+        float* wq = reinterpret_cast<float*>(thi);                // [16][E] floats
+#pragma unroll
+        for (int t = 0; t < G::DT; ++t)
+            *reinterpret_cast<f32x4*>(wq + c16 * E_ + 16 * t + 4 * g) = accq[t];
+    }
+    __syncthreads();
+    const size_t pbase = (size_t)b * splits + split;
+    for (int idx = threadIdx.x; idx < n_q * E_; idx += WAVES * 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) a += reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[idx];
+        part_dqk[pbase * n_q * E_ + idx] = a;
+    }
+}
+
+__global__ void coattn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int per_slide, int splits) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_slide) return;
+    float a = 0.f;
+    for (int s = 0; s < splits; ++s) a += part[((size_t)b * splits + s) * per_slide + i];
+    out[(size_t)b * per_slide + i] = a;
+}
+
+// out[r] = a[r] . b[r]
+__global__ void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int rows, int cols) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int c = threadIdx.x & 63; c < cols; c += 64) s += a[(size_t)r * cols + c] * b[(size_t)r * cols + c];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) out[r] = s;
+}
+
+// delta[b][q] (+)= sum_m A[q][m] dA[q][m] over one slide's ragged [n_q][M_b] block
+__global__ void map_rowdot_kernel(const float* __restrict__ a_map, const float* __restrict__ da_map, const int* __restrict__ cu,
+                                  float* __restrict__ delta, int n_q, int accumulate) {
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
+    const size_t base = (size_t)n_q * row_begin + (size_t)q * m_rows;
+    float s = 0.f;
+    for (int m = threadIdx.x; m < m_rows; m += blockDim.x) s += a_map[base + m] * da_map[base + m];
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        float* d = delta + (size_t)b * n_q + q;
+        *d = accumulate ? *d + t : t;
+    }
+}
+
+}  // namespace
+
+int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
+                          const float* qk2, const float* lse2, const float* dctx, const float* delta,
+                          const float* a_map, const float* da_map,
+                          void* dbag, float* part_dqk, int n_q, int splits, hipStream_t stream) {
+    (void)a_map;
+    dim3 grid(splits, n_slides);
+#define MPO_BWD_CASE(EV)                                                                                     \
+    case EV:                                                                                                 \
+        if (bag_f32)                                                                                         \
+            coattn_bwd_kernel<EV, true><<<grid, BwdCfg<EV, true>::WAVES * 64, 0, stream>>>(                  \
+                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, splits);                       \
+        else                                                                                                 \
+            coattn_bwd_kernel<EV, false><<<grid, BwdCfg<EV, false>::WAVES * 64, 0, stream>>>(                \
+                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, splits);                       \
+        break;
+    switch (embed) {
+        MPO_BWD_CASE(128)
+        MPO_BWD_CASE(256)
+        default:
+            mpo_set_error("coattn backward: embed_dim %d not in {128,256}", embed);
+            return 1;
+    }
+#undef MPO_BWD_CASE
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, int splits,
+                                 hipStream_t stream) {
+    const int per = n_q * embed;
+    dim3 grid((per + 255) / 256, n_slides);
+    coattn_bwd_reduce_kernel<<<grid, 256, 0, stream>>>(part_dqk, dqk, per, splits);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_rowdot(const float* a, const float* b, float* out, int rows, int cols, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    rowdot_kernel<<<(rows + 3) / 4, 256, 0, stream>>>(a, b, out, rows, cols);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_map_rowdot(const float* a_map, const float* da_map, const int* cu, float* delta, int n_slides, int n_q,
+                          int accumulate, hipStream_t stream) {
+    dim3 grid(n_q, n_slides);
+    map_rowdot_kernel<<<grid, 256, 0, stream>>>(a_map, da_map, cu, delta, n_q, accumulate);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}

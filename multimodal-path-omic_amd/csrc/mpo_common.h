@@ -1,0 +1,66 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of the fusion path.
+// Wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
+
+static constexpr float kLog2e = 1.4426950408889634f;
+static constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }          // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+__device__ __forceinline__ float bf2f(__bf16 h) { return (float)h; }
+
+// x = hi + lo with both parts bf16: ~16 mantissa bits survive an MFMA that takes bf16 operands.
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- counter-based RNG for dropout masks (Philox4x32-10; seed + 64-bit element counter) ----
+// Forward and backward regenerate the same mask from (seed, offset, element index); nothing is stored.
+__device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// keep-scale for element `idx` of a stream identified by (seed, stream): 0 or 1/(1-p)
+__device__ __forceinline__ float dropout_keep(uint64_t seed, uint64_t offset, uint64_t idx, float p, float inv_keep) {
+    uint64_t ctr = offset + (idx >> 2);
+    uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+    float u = (float)(w >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.0f;
+}
+
+// ---- host-side error plumbing (one definition in capi.hip) ----
+void mpo_set_error(const char* fmt, ...);
+#define MPO_CHECK(cond, ...) do { if (!(cond)) { mpo_set_error(__VA_ARGS__); return 1; } } while (0)
+#define MPO_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    mpo_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+#define MPO_LAUNCH_CHECK() MPO_HIP(hipGetLastError())

@@ -1,0 +1,155 @@
+"""GPU parity of K1 (MCAT co-attention, HIP) against the oracle and the reference's golden vectors.
+
+Calls go through the drop-in module -> autograd Function -> C ABI (libmpo_hip.so).
+Tolerances: north star = 1e-3 in fp32.  Attention maps are compared RELATIVELY.
+For a bf16-stored bag the oracle is fed the same bf16-rounded values (bf16 is a storage format of
+the INPUT; arithmetic stays fp32-accurate through hi/lo operand splitting), the bag gradient is
+rounded to bf16 by construction and gets a bf16-sized tolerance.
+"""
+import pytest
+import torch
+
+import cases as C
+from multimodal_path_omic_amd import synthetic as syn
+from multimodal_path_omic_amd.blocks import CoAttention
+from multimodal_path_omic_amd.ops import BagBatch, linear
+from oracle import mpo_oracle as O
+
+pytestmark = pytest.mark.gpu
+sub = syn.subsample
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def make_module(seed, gain, dev):
+    sd = syn.fill_state_dict(C.MCAT_COATTN_SHAPES, seed, gain)
+    mod = CoAttention(C.E, 1)
+    mod.load_state_dict({k[len("co_attention."):]: v for k, v in sd.items()}, strict=True)
+    return mod.to(dev), {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+
+def oracle_grads(loss, named):
+    gs = torch.autograd.grad(loss, [t for _, t in named], allow_unused=True, retain_graph=True)
+    return {n: (torch.zeros_like(t) if g is None else g) for (n, t), g in zip(named, gs)}
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "elu", "tanh", "sigmoid"])
+@pytest.mark.parametrize("rows,i,o", [(6, 256, 256), (192, 256, 768), (7, 100, 256), (33, 512, 4)])
+def test_linear_matches_torch(dev, act, rows, i, o):
+    g = syn.rng(11)
+    x = syn.normal(g, (rows, i)).to(dev).requires_grad_(True)
+    w = syn.normal(g, (o, i), 0.1).to(dev).requires_grad_(True)
+    b = syn.normal(g, (o,)).to(dev).requires_grad_(True)
+    probe = syn.normal(g, (rows, o)).to(dev)
+    y = linear(x, w, b, act)
+    f = {"none": lambda t: t, "relu": torch.relu, "elu": torch.nn.functional.elu, "tanh": torch.tanh,
+         "sigmoid": torch.sigmoid}[act]
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    y64 = f(x64 @ w64.t() + b64)
+    assert relerr(y, y64) < 1e-5
+    gy = torch.autograd.grad((y * probe).sum(), [x, w, b])
+    g64 = torch.autograd.grad((y64 * probe.double()).sum(), [x64, w64, b64])
+    for a, r in zip(gy, g64):
+        assert relerr(a, r) < 1e-5
+
+
+@pytest.mark.parametrize("case", list(C.COATTN_CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_coattn_forward_backward(dev, golden, case, dtype):
+    m, gain, seed = C.COATTN_CASES[case]
+    mod, p = make_module(seed, gain, dev)
+    q, bag, p_out, p_a = C.coattn_inputs(m, seed + 1)
+    bag_in = bag.to(dtype)                                    # what the kernel stores/reads
+    # ---- oracle on exactly the values the kernel sees
+    qo = q.clone().requires_grad_(True)
+    bo = bag_in.float().clone().requires_grad_(True)
+    out_o, a_o = O.mcat_coattention(qo, bo, p, need_weights=True)
+    named = [("query", qo), ("bag", bo)] + list(p.items())
+    g1_o = oracle_grads((out_o * p_out).sum() + (a_o * p_a).sum(), named)
+    g0_o = oracle_grads((out_o * p_out).sum(), named)
+
+    qd = q.to(dev).requires_grad_(True)
+    bd = bag_in.to(dev).requires_grad_(True)
+    # training-style call (no map), models/mcat/mcat.py:97 with inference=False
+    out0, a0 = mod(query=qd, key=bd, value=bd, need_weights=False)
+    assert a0 is None
+    out1, a1 = mod(query=qd, key=bd, value=bd, need_weights=True)
+    assert a1.shape == (C.N_OMIC, m)
+    assert relerr(out0, out_o) < 1e-4, relerr(out0, out_o)
+    assert relerr(out1, out_o) < 1e-4
+    # attention map: relative, element-wise
+    rel_a = ((a1.detach().cpu() - a_o.detach()).abs() / a_o.detach().clamp_min(1e-30)).max().item()
+    assert rel_a < 1e-3, rel_a
+    torch.testing.assert_close(a1.sum(1).cpu(), torch.ones(C.N_OMIC), rtol=1e-4, atol=1e-4)
+
+    params = dict(mod.named_parameters())
+    tensors = [qd, bd] + [params[k[len("co_attention."):]] for k in p]
+    names = ["query", "bag"] + list(p)
+    bag_tol = 1e-3 if dtype == torch.float32 else 1.5e-2       # d_bag is emitted in the bag's dtype
+    for tag, loss, ref in (("grad0", (out0 * p_out.to(dev)).sum(), g0_o),
+                           ("grad1", (out1 * p_out.to(dev)).sum() + (a1 * p_a.to(dev)).sum(), g1_o)):
+        gs = torch.autograd.grad(loss, tensors, retain_graph=True)
+        for n, gr in zip(names, gs):
+            tol = bag_tol if n == "bag" else 1e-3
+            e = relerr(gr, ref[n]) if ref[n].abs().max() > 0 else float(gr.abs().max())
+            assert e < tol, (tag, n, e)
+
+    if dtype == torch.float32:
+        # the reference's own numbers (golden vectors), fp32 bag only
+        g = golden("coattn_mcat")
+        assert relerr(out1, g[f"{case}/out"]) < 1e-3
+        ga = g[f"{case}/A_sub"]
+        assert ((sub(a1).cpu() - ga).abs() / ga.clamp_min(1e-30)).max().item() < 1e-3
+        gs = torch.autograd.grad((out1 * p_out.to(dev)).sum() + (a1 * p_a.to(dev)).sum(), tensors)
+        for n, gr in zip(names, gs):
+            ref = g[f"{case}/grad1/{n}"]
+            if ref.abs().max() > 0:
+                assert relerr(sub(gr), ref) < 2e-3, (n, relerr(sub(gr), ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_coattn_ragged_window_equals_per_slide(dev, dtype):
+    """A window of slides in ONE ragged launch gives each slide the result of its own call."""
+    lengths = [1, 31, 32, 33, 500, 4097, 129]
+    mod, p = make_module(77, 2.0, dev)
+    g = syn.rng(78)
+    bags = [torch.clamp(syn.normal(g, (m, C.E)), min=0).to(dtype).to(dev) for m in lengths]
+    query = syn.normal(g, (len(lengths), C.N_OMIC, C.E)).to(dev).requires_grad_(True)
+    batch = BagBatch.from_list(bags)
+    data = batch.data.clone().requires_grad_(True)
+    out_w, maps = mod.forward_window(query, batch.with_data(data), need_weights=True)
+    probe = syn.normal(g, (len(lengths), C.N_OMIC, C.E)).to(dev)
+    gq, gb, gw = torch.autograd.grad((out_w * probe).sum(), [query, data, mod.in_proj_weight])
+    off = 0
+    gw_sum = torch.zeros_like(gw)
+    for i, bag in enumerate(bags):
+        qi = query[i].detach().clone().requires_grad_(True)
+        bi = bag.clone().requires_grad_(True)
+        o_i, a_i = mod(query=qi, key=bi, value=bi, need_weights=True)
+        assert relerr(out_w[i], o_i) < 1e-5
+        assert relerr(maps[i], a_i) < 1e-5
+        # and against the oracle
+        o_o, a_o = O.mcat_coattention(qi.detach().cpu(), bag.float().cpu(), {k: v.detach() for k, v in p.items()})
+        assert relerr(o_i, o_o) < 1e-4
+        assert ((a_i.cpu() - a_o).abs() / a_o.clamp_min(1e-30)).max().item() < 1e-3
+        gqi, gbi, gwi = torch.autograd.grad((o_i * probe[i]).sum(), [qi, bi, mod.in_proj_weight])
+        assert relerr(gq[i], gqi) < 1e-5
+        assert relerr(gb[off:off + lengths[i]], gbi) < 1e-5
+        gw_sum += gwi
+        off += lengths[i]
+    assert relerr(gw, gw_sum) < 1e-4
+
+
+def test_coattn_rejects_bad_arguments(dev):
+    mod, _ = make_module(1, 1.0, dev)
+    q = torch.zeros(C.N_OMIC, C.E, device=dev)
+    bag = torch.zeros(10, C.E, device=dev)
+    with pytest.raises(NotImplementedError):
+        mod(query=q, key=bag, value=bag.clone())
+    with pytest.raises(RuntimeError):
+        mod(query=q.cpu(), key=bag.cpu(), value=bag.cpu())          # no CPU fallback
+    with pytest.raises(RuntimeError):
+        mod(query=torch.zeros(17, C.E, device=dev), key=bag, value=bag)   # > 16 queries
