@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: whole-model slides/sec (forward + backward + optimiser step) on synthetic
+15k-patch bags (BASELINE.json configs[1]: MCAT, bf16-stored 15000 x 1024 patch bag + 6 x 256 omic
+tokens), one process per GPU, RCCL gradient all-reduce once per optimiser step.
+
+A "step" = one gradient-accumulation window of --window slides per rank pushed through the model as
+one ragged batch (loss = ces, models/loss.py:5-28), gradients all-reduced, Adam step.  Prints ONE
+JSON line (rank 0) with the contract fields plus `roofline` (the K1 bag-pass kernel timed by HIP
+events on its own stream against algorithmic bytes) and `cpu_baseline` (the CPU oracle timed on
+this box's host cores on a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="mcat", choices=["mcat", "nacagat"])
+    ap.add_argument("--window", type=int, default=32, help="slides per rank per optimiser step (grad_acc_step)")
+    ap.add_argument("--patches", type=int, default=15000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--n-windows", type=int, default=2, help="distinct resident windows cycled (working set >> 256 MB L3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(kind, dev, bag_dtype):
+    from multimodal_path_omic_amd.models import (MultimodalCoAttentionTransformer,
+                                                 NarrowContextualAttentionGateTransformer)
+    torch.manual_seed(0)
+    cls = MultimodalCoAttentionTransformer if kind == "mcat" else NarrowContextualAttentionGateTransformer
+    return cls(omic_sizes=[256] * 6, model_size="medium", bag_dtype=bag_dtype).to(dev).train()
+
+
+def make_windows(n_windows, window, patches, dev, bag_dtype, seed):
+    """Synthetic N(0,1) patch features generated on the device (seeded), labels/censorship cycling
+    (i mod 4, i mod 2) as SURVEY 8(d) prescribes."""
+    from multimodal_path_omic_amd.ops import BagBatch, make_cu
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = []
+    for w in range(n_windows):
+        data = torch.randn(window * patches, 1024, device=dev, dtype=torch.float32, generator=g).to(bag_dtype)
+        lengths = [patches] * window
+        bags = BagBatch(data, make_cu(lengths, dev), lengths)
+        omics = [torch.randn(window, 256, device=dev, generator=g) for _ in range(6)]
+        idx = torch.arange(window, device=dev) + w * window
+        out.append((bags, omics, idx % 4, (idx % 2).float()))
+    return out
+
+
+def roofline_leg(dev, window, patches, bag_dtype, reps=20):
+    """Time the K1 forward bag-pass kernel alone (HIP events on the launching stream) over a window
+    of H_bag-like bags; algorithmic bytes = M*d*e per slide."""
+    from multimodal_path_omic_amd import _lib as L
+    from multimodal_path_omic_amd.ops import make_cu
+    E, n_q = 256, 6
+    esz = 2 if bag_dtype == torch.bfloat16 else 4
+    lengths = [patches] * window
+    cu = make_cu(lengths, dev)
+    bags = [torch.relu(torch.randn(window * patches, E, device=dev)).to(bag_dtype) for _ in range(2)]
+    qk2 = torch.randn(window * n_q, E, device=dev) * 0.05
+    lib = L.lib()
+    splits = lib.mpo_coattn_splits(window, patches)
+    part_ml = torch.empty(window * splits * 32, device=dev)
+    part_ctx = torch.empty(window * splits * n_q * E, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def launch(i):
+        L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), L.bag_dtype_code(bags[0]), L.ptr(cu), window, E,
+                                           L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, splits,
+                                           stream.cuda_stream), "mpo_coattn_fwd_bagpass")
+    for i in range(3):
+        launch(i)
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for i, (s, e) in enumerate(evs):
+        s.record(stream)
+        launch(i)
+        e.record(stream)
+    torch.cuda.synchronize(dev)
+    us = sorted(s.elapsed_time(e) * 1e3 for s, e in evs)
+    avg_us = sum(us) / len(us)
+    alg_bytes = window * patches * E * esz
+    achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "k1_fwd_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    return {"bound": "hbm", "kernel": "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32"),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_us, 2),
+            "min_launch_us": round(us[0], 2), "launches_timed": reps}
+
+
+def cpu_baseline_leg(kind, patches, budget_s=15.0):
+    """The CPU oracle (kind 'port': PyTorch-CPU restatement pinned to the reference by golden
+    vectors) on this box's host cores: whole-model forward + ces + backward, fp32, one slide at a
+    time like the reference loop."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases as C
+    from multimodal_path_omic_amd import synthetic as syn
+    from oracle import mpo_oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    sd = syn.fill_state_dict(C.model_shapes([256] * 6, kind == "nacagat"), 1)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    wsi = syn.make_bag(patches, 1235)
+    omics = syn.make_omics([256] * 6, 1236)
+    fwd = O.mcat_forward if kind == "mcat" else O.nacagat_forward
+
+    def one():
+        hz, sv, _, _ = fwd(p, wsi, omics)
+        O.ces_loss(hz, sv, torch.tensor([1]), torch.tensor([0.0])).backward()
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "slides/s", "cores": threads, "kind": "port",
+            "sample": f"{n} slides of {patches}x1024 fp32, {kind} medium, fwd+ces+bwd, one slide per call"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    bag_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+
+    from multimodal_path_omic_amd.dp import FlatGradBucket
+    from multimodal_path_omic_amd.harness import train_window
+    model = build_model(a.model, dev, bag_dtype)
+    bucket = FlatGradBucket(list(model.parameters()))
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, fused=True)   # config.yaml:57-63
+    windows = make_windows(a.n_windows, a.window, a.patches, dev, bag_dtype, seed=1234 + rank)
+
+    def step(i):
+        bags, omics, labels, cens = windows[i % len(windows)]
+        bucket.zero()
+        train_window(model, bags, omics, labels, cens, a.window)
+        bucket.all_reduce_mean()
+        opt.step()
+
+    for i in range(a.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        slides = world * a.window * a.steps
+        out = {
+            "metric": "slides/sec (fwd+bwd) at 15k-patch bags", "value": round(slides / dt, 2), "unit": "slides/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.model.upper()} medium whole model fwd+bwd+Adam, {a.patches}x1024 {a.dtype} patch bag "
+                                   f"+ 6x256 omic tokens per slide, ces loss", "slides_per_rank_per_step": a.window,
+                       "global_slides_per_step": world * a.window, "patches_per_slide": a.patches,
+                       "parallelism": f"dp{world}", "resident_windows": a.n_windows},
+        }
+        out["roofline"] = roofline_leg(dev, a.window, a.patches, bag_dtype)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(a.model, a.patches)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,18 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                              float* d_out_proj_weight, float* d_out_proj_bias,
                              void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
+/* ---- the two bag-pass kernels of K1 on their own (bench.py times them with HIP events for the
+ * roofline line; tests use them for kernel-level checks).  qk2 = log2(e) * (q/sqrt(E)) W_k, [n_slides*n_q, embed].
+ * part_ml [n_slides*splits*32], part_ctx [n_slides*splits*n_q*embed] with splits = mpo_coattn_splits(). */
+int mpo_coattn_splits(int n_slides, int max_rows);
+int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
+                           const float* qk2, float* part_ml, float* part_ctx, float* raw_logits /* nullable */,
+                           int n_q, int splits, mpo_stream_t stream);
+int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
+                           const float* qk2, const float* lse2, const float* dctx, const float* delta,
+                           const float* d_attn_map /* nullable */, void* d_bag, float* part_dqk,
+                           int n_q, int splits, mpo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

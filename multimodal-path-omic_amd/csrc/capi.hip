@@ -33,9 +33,10 @@ struct Arena {
 };
 static inline size_t arena_need(size_t acc, size_t n_floats) { return align_up(acc, 256) + n_floats * 4; }
 
-int mpo_coattn_splits(int n_slides, int max_rows) {
+extern "C" int mpo_coattn_splits(int n_slides, int max_rows) {
     // ~4 workgroups per CU over the window; at least one 32-row tile per wave of a workgroup
     int s = (1024 + n_slides - 1) / n_slides;
+    if (s > 512) s = 512;
     const int cap = (max_rows + 127) / 128;
     if (s > cap) s = cap;
     if (s < 1) s = 1;
@@ -177,6 +178,20 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
     if ((rc = mpo_linear_bwd_input(dq_pre, w_q, d_query, R, E, E, 1.0f, 0, stream))) return rc;
     if ((rc = mpo_linear_bwd_weight(dq_pre, query, d_in_w, d_in_b, R, E, E, 1.0f, stream))) return rc;
     return 0;
+}
+
+int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
+                           const float* qk2, float* part_ml, float* part_ctx, float* raw_logits, int n_q, int splits,
+                           mpo_stream_t stream) {
+    return mpo_launch_coattn_fwd_partial(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, part_ml, part_ctx,
+                                         raw_logits, n_q, splits, stream);
+}
+int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
+                           const float* qk2, const float* lse2, const float* dctx, const float* delta,
+                           const float* d_attn_map, void* d_bag, float* part_dqk, int n_q, int splits,
+                           mpo_stream_t stream) {
+    return mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, lse2, dctx, delta, nullptr,
+                                 d_attn_map, d_bag, part_dqk, n_q, splits, stream);
 }
 
 }  // extern "C"

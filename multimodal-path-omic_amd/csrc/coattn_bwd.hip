@@ -255,13 +255,25 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
     }
 }
 
-__global__ void coattn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int per_slide, int splits) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per_slide) return;
-    float a = 0.f;
-    for (int s = 0; s < splits; ++s) a += part[((size_t)b * splits + s) * per_slide + i];
-    out[(size_t)b * per_slide + i] = a;
+// dqk[b][i] = sum_s part[b][s][i]: 64 float4 columns per workgroup, the 4 waves split the splits
+__global__ __launch_bounds__(256)
+void coattn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int per_slide, int splits) {
+    __shared__ __attribute__((aligned(16))) float red[4][256];
+    const int b = blockIdx.y, c = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i4 = blockIdx.x * 64 + c;                       // float4 index inside the slide's block
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (4 * i4 < per_slide)
+        for (int s = w; s < splits; s += 4)
+            a += *reinterpret_cast<const f32x4*>(part + ((size_t)b * splits + s) * per_slide + 4 * i4);
+    *reinterpret_cast<f32x4*>(&red[w][4 * c]) = a;
+    __syncthreads();
+    if (w == 0 && 4 * i4 < per_slide) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(&red[0][4 * c]);
+        t += *reinterpret_cast<const f32x4*>(&red[1][4 * c]);
+        t += *reinterpret_cast<const f32x4*>(&red[2][4 * c]);
+        t += *reinterpret_cast<const f32x4*>(&red[3][4 * c]);
+        *reinterpret_cast<f32x4*>(out + (size_t)b * per_slide + 4 * i4) = t;
+    }
 }
 
 // out[r] = a[r] . b[r]
@@ -325,7 +337,7 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
 int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, int splits,
                                  hipStream_t stream) {
     const int per = n_q * embed;
-    dim3 grid((per + 255) / 256, n_slides);
+    dim3 grid((per / 4 + 63) / 64, n_slides);
     coattn_bwd_reduce_kernel<<<grid, 256, 0, stream>>>(part_dqk, dqk, per, splits);
     MPO_LAUNCH_CHECK();
     return 0;

@@ -184,27 +184,51 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
 }
 
 // Merge the split partials of one (slide, query): ctx = sum_s 2^(m_s - m) ctx_s / l,  lse2 = m + log2 l.
+// One workgroup per (query, slide); the splits (<= 1024) are spread over the threads: weights go
+// through LDS, the context is summed as float4 columns x split groups and reduced across the groups.
 template <int E_>
-__global__ void coattn_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_ctx,
-                                      float* __restrict__ ctx, float* __restrict__ lse2, int n_q, int splits) {
-    const int q = blockIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(256)
+void coattn_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_ctx,
+                           float* __restrict__ ctx, float* __restrict__ lse2, int n_q, int splits) {
+    constexpr int DG = E_ / 4;                 // float4 columns
+    constexpr int NSG = 256 / DG;              // split groups (E=256: 4)
+    __shared__ float wts[1024];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float accs[NSG][E_];
+    const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const size_t p0 = (size_t)b * splits;
     float mt = -INFINITY;
-    for (int s = 0; s < splits; ++s) mt = fmaxf(mt, part_ml[(p0 + s) * 32 + 2 * q]);
+    for (int s = tid; s < splits; s += 256) mt = fmaxf(mt, part_ml[(p0 + s) * 32 + 2 * q]);
+    mt = wave_max(mt);
+    if ((tid & 63) == 0) red[tid >> 6] = mt;
+    __syncthreads();
+    mt = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float lt = 0.f;
-    for (int s = 0; s < splits; ++s) {
+    for (int s = tid; s < splits; s += 256) {
         const float ms = part_ml[(p0 + s) * 32 + 2 * q];
-        if (ms != -INFINITY) lt += __builtin_amdgcn_exp2f(ms - mt) * part_ml[(p0 + s) * 32 + 2 * q + 1];
+        const float w = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - mt);
+        wts[s] = w;
+        lt += w * part_ml[(p0 + s) * 32 + 2 * q + 1];
     }
-    for (int d = threadIdx.x; d < E_; d += blockDim.x) {
-        float a = 0.f;
-        for (int s = 0; s < splits; ++s) {
-            const float ms = part_ml[(p0 + s) * 32 + 2 * q];
-            if (ms != -INFINITY) a += __builtin_amdgcn_exp2f(ms - mt) * part_ctx[((p0 + s) * n_q + q) * E_ + d];
-        }
-        ctx[((size_t)b * n_q + q) * E_ + d] = a / lt;
+    lt = wave_sum(lt);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = lt;
+    __syncthreads();
+    lt = red[4] + red[5] + red[6] + red[7];
+    const int dg = tid % DG, sg = tid / DG;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = sg; s < splits; s += NSG) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part_ctx + ((p0 + s) * n_q + q) * E_ + 4 * dg);
+        a += v * wts[s];
     }
-    if (threadIdx.x == 0) lse2[(size_t)b * n_q + q] = mt + __builtin_amdgcn_logf(lt);
+    *reinterpret_cast<f32x4*>(&accs[sg][4 * dg]) = a;
+    __syncthreads();
+    for (int d = tid; d < E_; d += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < NSG; ++g) t += accs[g][d];
+        ctx[((size_t)b * n_q + q) * E_ + d] = t / lt;
+    }
+    if (tid == 0) lse2[(size_t)b * n_q + q] = mt + __builtin_amdgcn_logf(lt);
 }
 
 // A[n][m] = 2^(S2[n][m] - lse2[n]) in place over the ragged [n_q][M_b] blocks; optional
@@ -254,9 +278,10 @@ int mpo_launch_coattn_fwd_partial(const void* bag, int bag_f32, const int* cu, i
 
 int mpo_launch_coattn_combine(const float* part_ml, const float* part_ctx, float* ctx, float* lse2,
                               int n_slides, int n_q, int embed, int splits, hipStream_t stream) {
+    MPO_CHECK(splits <= 1024, "coattn combine: splits %d > 1024", splits);
     dim3 grid(n_q, n_slides);
     switch (embed) {
-        case 128: coattn_combine_kernel<128><<<grid, 128, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, splits); break;
+        case 128: coattn_combine_kernel<128><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, splits); break;
         case 256: coattn_combine_kernel<256><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, splits); break;
         case 512: coattn_combine_kernel<512><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, splits); break;
         default: mpo_set_error("coattn: embed_dim %d not in {128,256,512}", embed); return 1;

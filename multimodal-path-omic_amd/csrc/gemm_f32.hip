@@ -11,15 +11,18 @@
 // Epilogue: activation, optional keep-mask multiply (dropout), optional residual add, optional
 // accumulate into C (beta = 1).
 //
-// Tile: 16 rows x 128 columns per 256-thread workgroup (4 waves x 16x32), K step 32, operands staged in
-// LDS as [row][k] with a 34-float row stride (conflict-free ds_read_b32 for the 16x16x4 operand map:
-// lane l reads row l&15, k = 4*kk + (l>>4)).
+// Tile: 32 x 32 outputs per 256-thread workgroup (4 waves x 16x16), and a whole K chunk of up to 256
+// staged at once: every global load of a chunk is in flight together (these GEMMs are a few hundred KB
+// and launch/latency-bound, not bandwidth-bound), the next chunk is prefetched into registers while the
+// MFMAs of the current one run.  LDS image [row][k], row stride 264 floats: the operand read is one
+// conflict-free ds_read_b128 per four MFMAs (lane (i = l&15, kq = l>>4) takes k = 16kk + 4kq + j for the
+// j-th MFMA of the block; any partition of k is valid as long as A and B agree).
 #include "mpo_common.h"
 #include "mpo_kernels.h"
 
 namespace {
 
-constexpr int BM = 16, BN = 128, BK = 32, LDT = BK + 2;
+constexpr int BM = 32, BN = 32, KC = 256, LDK = KC + 8;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -31,58 +34,105 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// One operand tile (32 rows x KC k) in flight in registers: 8 float4 per thread.
+template <bool KCONTIG>
+struct OperandStage {
+    f32x4 v[8];
+    // element (mn, k) lives at p[mn*ld + k] (KCONTIG) or p[k*ld + mn]
+    __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int mn0, int mn_lim, int k0, int k_lim,
+                                         bool vec_ok, int tid) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = i * 256 + tid;
+            int mn, k;
+            if (KCONTIG) { mn = f >> 6; k = (f & 63) << 2; } else { k = f >> 3; mn = (f & 7) << 2; }
+            const int gmn = mn0 + mn, gk = k0 + k;
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (KCONTIG) {
+                if (gmn < mn_lim) {
+                    const float* q = p + (size_t)gmn * ld + gk;
+                    if (vec_ok && gk + 3 < k_lim) r = *reinterpret_cast<const f32x4*>(q);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gk + j < k_lim) r[j] = q[j];
+                    }
+                }
+            } else {
+                if (gk < k_lim) {
+                    const float* q = p + (size_t)gk * ld + gmn;
+                    if (vec_ok && gmn + 3 < mn_lim) r = *reinterpret_cast<const f32x4*>(q);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gmn + j < mn_lim) r[j] = q[j];
+                    }
+                }
+            }
+            v[i] = r;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = i * 256 + tid;
+            if (KCONTIG) {
+                *reinterpret_cast<f32x4*>(lds + (f >> 6) * LDK + ((f & 63) << 2)) = v[i];
+            } else {
+                const int k = f >> 3, mn = (f & 7) << 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lds[(mn + j) * LDK + k] = v[i][j];
+            }
+        }
+    }
+};
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256)
 void gemm_f32_kernel(GemmArgs g) {
-    __shared__ float As[BM * LDT];
-    __shared__ float Bs[BN * LDT];
+    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const float* __restrict__ A = g.A;
-    const float* __restrict__ B = g.B;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
+    const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+
+    OperandStage<A_KC> sa;
+    OperandStage<B_KC> sb;
+    sa.load(g.A, g.lda, m0, g.M, 0, g.K, a_vec, tid);
+    sb.load(g.B, g.ldb, n0, g.N, 0, g.K, b_vec, tid);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        // ---- stage A tile (16 x 32)
-        for (int e = tid; e < BM * BK; e += 256) {
-            int m, k;
-            if (A_KC) { m = e / BK; k = e % BK; } else { k = e / BM; m = e % BM; }
-            const int gm = m0 + m, gk = k0 + k;
-            float v = 0.f;
-            if (gm < g.M && gk < g.K) v = A_KC ? A[(size_t)gm * g.lda + gk] : A[(size_t)gk * g.lda + gm];
-            As[m * LDT + k] = v;
-        }
-        // ---- stage B tile (128 x 32)
-        for (int e = tid; e < BN * BK; e += 256) {
-            int n, k;
-            if (B_KC) { n = e / BK; k = e % BK; } else { k = e / BN; n = e % BN; }
-            const int gn = n0 + n, gk = k0 + k;
-            float v = 0.f;
-            if (gn < g.N && gk < g.K) v = B_KC ? B[(size_t)gn * g.ldb + gk] : B[(size_t)gk * g.ldb + gn];
-            Bs[n * LDT + k] = v;
+    for (int k0 = 0; k0 < g.K; k0 += KC) {
+        sa.store(As, tid);
+        sb.store(Bs, tid);
+        if (k0 + KC < g.K) {                                    // next chunk flies under this chunk's MFMAs
+            sa.load(g.A, g.lda, m0, g.M, k0 + KC, g.K, a_vec, tid);
+            sb.load(g.B, g.ldb, n0, g.N, k0 + KC, g.K, b_vec, tid);
         }
         __syncthreads();
-        const float* ap = As + (lane & 15) * LDT + (lane >> 4);
-        const float* bp = Bs + (wave * 32 + (lane & 15)) * LDT + (lane >> 4);
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const float a = ap[4 * kk];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[4 * kk], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[16 * LDT + 4 * kk], acc1, 0, 0, 0);
+        const int kblocks = (min(KC, g.K - k0) + 15) >> 4;
+        const float* ap = As + (16 * wm + i16) * LDK + 4 * kq;
+        const float* bp = Bs + (16 * wn + i16) * LDK + 4 * kq;
+        for (int kk = 0; kk < kblocks; ++kk) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 16 * kk);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 16 * kk);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
         }
         __syncthreads();
     }
     // ---- epilogue: D col = lane&15, row = 4*(lane>>4) + r
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int n = n0 + wave * 32 + 16 * c + (lane & 15);
-        if (n >= g.N) continue;
+    const int n = n0 + 16 * wn + i16;
+    if (n < g.N) {
         const float bias = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 4 * (lane >> 4) + r;
+            const int m = m0 + 16 * wm + 4 * kq + r;
             if (m >= g.M) continue;
-            float v = ((c == 0 ? acc0[r] : acc1[r]) + bias) * g.alpha;
+            float v = (acc0[r] + acc1[r] + bias) * g.alpha;
             v = apply_act(v, g.act);
             const size_t o = (size_t)m * g.ldc + n;
             if (g.mask) v *= g.mask[o];
@@ -93,13 +143,20 @@ void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-// colsum[n] (+)= sum_m X[m][n]   (bias gradients)
+// colsum[n] (+)= sum_m X[m][n]   (bias gradients): 64 columns per workgroup, 4 waves split the rows
 __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int ld, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += x[(size_t)m * ld + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N)
+        for (int m = w; m < M; m += 4) s += x[(size_t)m * ld + n];
+    red[w][c] = s;
+    __syncthreads();
+    if (w == 0 && n < N) {
+        const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        out[n] = accumulate ? out[n] + t : t;
+    }
 }
 
 }  // namespace
@@ -118,7 +175,7 @@ int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream) {
 
 int mpo_launch_colsum(const float* x, float* out, int M, int N, int ld, int accumulate, hipStream_t stream) {
     if (N <= 0) return 0;
-    colsum_kernel<<<(N + 255) / 256, 256, 0, stream>>>(x, out, M, N, ld, accumulate);
+    colsum_kernel<<<(N + 63) / 64, 256, 0, stream>>>(x, out, M, N, ld, accumulate);
     MPO_LAUNCH_CHECK();
     return 0;
 }

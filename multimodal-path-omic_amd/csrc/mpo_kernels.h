@@ -52,7 +52,7 @@ inline int mpo_linear_bwd_weight(const float* dy, const float* x, float* dw, flo
 }
 
 // ---- K1/K2 long-bag cross-attention (coattn_fwd.hip / coattn_bwd.hip)
-int mpo_coattn_splits(int n_slides, int max_rows);
+extern "C" int mpo_coattn_splits(int n_slides, int max_rows);
 int mpo_launch_coattn_fwd_partial(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                                   const float* qk2, float* part_ml, float* part_ctx, float* s_out,
                                   int n_q, int splits, hipStream_t stream);

@@ -1,0 +1,75 @@
+"""Caller-side semantics of the reference's train()/validate() loops (row H9 of SURVEY.md section
+8(a); models/mcat/main.py:19-155), restated for window-batched execution: `ces` loss, risk score,
+gradient accumulation over `grad_acc_step` slides, Harrell's C-index.  No per-slide host sync
+(the reference's loss.item() at main.py:49 is exactly what this harness must not do)."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .ops import BagBatch
+
+
+def ces_loss(hazards, survs, label, censorship, alpha: float = 0.75, eps: float = 1e-7, reduction: str = "mean"):
+    """CrossEntropySurvivalLoss (models/loss.py:5-28) for B slides at once: hazards/survs (B,C),
+    label (B,) int64, censorship (B,) float.  reduction 'mean' | 'sum' | 'none' over slides."""
+    y = label.view(-1, 1).long()
+    c = censorship.view(-1, 1).float()
+    s_pad = torch.cat([torch.ones_like(c), survs], 1)
+    reg = -(1 - c) * (torch.log(torch.gather(s_pad, 1, y).clamp(min=eps))
+                      + torch.log(torch.gather(hazards, 1, y).clamp(min=eps)))
+    s_y = torch.gather(survs, 1, y).clamp(min=eps)
+    ce = -(c * torch.log(s_y) + (1 - c) * torch.log(1 - s_y))
+    loss = ((1 - alpha) * ce + alpha * reg).view(-1)
+    if reduction == "mean":
+        return loss.mean()
+    if reduction == "sum":
+        return loss.sum()
+    return loss
+
+
+def risk_score(survs):
+    """risk = -sum_j survs_j (models/mcat/main.py:56)."""
+    return -survs.sum(dim=1)
+
+
+def concordance_index_censored(event, time, risk, tied_tol: float = 1e-8) -> float:
+    """Harrell's C with scikit-survival's conventions (the reference calls
+    sksurv.metrics.concordance_index_censored, models/mcat/main.py:81): comparable pairs need an
+    event at the earlier time, or equal times with the other subject censored; risk ties within
+    tied_tol count one half.  Vectorised O(n^2) numpy."""
+    event = np.asarray(event, dtype=bool)
+    time = np.asarray(time, dtype=np.float64)
+    risk = np.asarray(risk, dtype=np.float64)
+    later = (time[None, :] > time[:, None]) | ((time[None, :] == time[:, None]) & ~event[None, :])
+    comparable = later & event[:, None]
+    np.fill_diagonal(comparable, False)
+    den = comparable.sum()
+    if den == 0:
+        raise ValueError("no comparable pairs")
+    diff = risk[:, None] - risk[None, :]
+    ties = np.abs(diff) <= tied_tol
+    num = ((diff > 0) & ~ties & comparable).sum() + 0.5 * (ties & comparable).sum()
+    return float(num) / float(den)
+
+
+def make_window(slides: Sequence[dict], device, bag_dtype=torch.float32):
+    """List of slide dicts (synthetic.make_cohort layout) -> (BagBatch, omics per group (B,d_i), labels, censorship)."""
+    bags = BagBatch.from_list([s["wsi"].to(device=device, dtype=bag_dtype, non_blocking=True) for s in slides])
+    n_groups = len(slides[0]["omics"])
+    omics = [torch.stack([s["omics"][i] for s in slides]).to(device, non_blocking=True) for i in range(n_groups)]
+    labels = torch.tensor([s["survival_class"] for s in slides], dtype=torch.int64).to(device, non_blocking=True)
+    cens = torch.tensor([float(s["censorship"]) for s in slides]).to(device, non_blocking=True)
+    return bags, omics, labels, cens
+
+
+def train_window(model, bags: BagBatch, omics, labels, cens, grad_acc_step: int):
+    """Forward + backward of one window; gradients ACCUMULATE into .grad with the reference's
+    1/grad_acc_step scaling per slide (models/mcat/main.py:69-70).  Returns (per-slide loss, risk) tensors
+    on the device -- no host sync."""
+    hazards, survs, _, _ = model.forward_window(bags, omics)
+    per_slide = ces_loss(hazards, survs, labels, cens, reduction="none")
+    (per_slide.sum() / grad_acc_step).backward()
+    return per_slide.detach(), risk_score(survs.detach())

@@ -1,0 +1,152 @@
+"""The two models of the hot path, composed from the drop-in layers (host composition = row H1 of
+SURVEY.md section 8(a)).  Class names, constructor arguments, attribute names (= state_dict keys) and
+forward() signatures follow models/mcat/mcat.py:12-142 and models/nacagat/nacagat.py:9-138, so a
+reference checkpoint loads with load_state_dict(strict=True) and the reference's train/validate/test
+loops can call these models unchanged.
+
+Beyond the reference's one-slide forward(), forward_window() pushes a whole gradient-accumulation
+window of slides through the model as ONE ragged batch: slides are independent (batch size 1, no
+cross-slide state: models/mcat/main.py:250), so per-slide results are unchanged while every launch is
+shared by the window.  `bag_dtype=torch.bfloat16` stores the patch matrix / H_bag in bf16 (a storage
+format: accumulation stays fp32, the 6 x d tail stays fp32 -- SURVEY.md section 0.7).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .blocks import AttentionNetGated, CoAttention, PreGatingContextualAttention
+from .fusion import ConcatFusion
+from . import ops
+from .ops import BagBatch
+from .transformer import make_set_transformer
+
+MODEL_SIZES = {"small": [128, 128], "medium": [256, 256], "big": [512, 512]}
+
+
+class _FusionModelBase(nn.Module):
+    def __init__(self, omic_sizes: Sequence[int], model_size: str, n_classes: int, dropout: float, fusion: str,
+                 device: str, bag_dtype: torch.dtype):
+        super().__init__()
+        self.n_classes = n_classes
+        self.model_sizes = MODEL_SIZES[model_size]
+        d0, d1 = self.model_sizes
+        self.bag_dtype = bag_dtype
+        # H: patch fully-connected layer (stock modules; fusing it into K1 is SURVEY 8(f) f1)
+        self.H = nn.Sequential(nn.Linear(1024, d0), nn.ReLU(), nn.Dropout(dropout))
+        # G: one 2-layer SNN per omic group
+        self.G = nn.ModuleList([
+            nn.Sequential(
+                nn.Sequential(nn.Linear(s, d0), nn.ELU(), nn.AlphaDropout(p=dropout, inplace=False)),
+                nn.Sequential(nn.Linear(d0, d1), nn.ELU(), nn.AlphaDropout(p=dropout, inplace=False)))
+            for s in omic_sizes])
+        self.co_attention = self._make_co_attention(d1)
+        self.path_transformer = make_set_transformer(d1, dropout)
+        self.path_attention_head = AttentionNetGated(n_classes=1, input_dim=d1, hidden_dim=d1)
+        self.path_rho = nn.Sequential(nn.Linear(d1, d1), nn.ReLU(), nn.Dropout(dropout))
+        self.omic_transformer = make_set_transformer(d1, dropout)
+        self.omic_attention_head = AttentionNetGated(n_classes=1, input_dim=d1, hidden_dim=d1)
+        self.omic_rho = nn.Sequential(nn.Linear(d1, d1), nn.ReLU(), nn.Dropout(dropout))
+        self.fusion = fusion
+        if fusion == "concat":
+            self.fusion_layer = ConcatFusion(dims=[d1, d1], hidden_size=d1, output_size=d1).to(device=device)
+        elif fusion in ("bilinear", "gated_concat"):
+            raise NotImplementedError(f"fusion '{fusion}' is a later row of the scope table (SURVEY.md 8(f) f4)")
+        else:
+            raise RuntimeError(f"Fusion mechanism {fusion} not implemented")
+        self.classifier = nn.Linear(d1, n_classes)
+
+    # ---- pieces
+    def _patch_fc(self, bags: BagBatch) -> BagBatch:
+        x = bags.data
+        lin = self.H[0]
+        if x.dtype == torch.bfloat16:
+            h = F.linear(x, lin.weight.to(torch.bfloat16), lin.bias.to(torch.bfloat16))
+        else:
+            h = F.linear(x.float(), lin.weight, lin.bias)
+        h = F.dropout(torch.relu(h), self.H[2].p, self.training)
+        return bags.with_data(h)
+
+    def _omic_fc(self, omics: "List[torch.Tensor]") -> torch.Tensor:
+        """omics: per group a (B, d_i) tensor -> G_bag (B, N, d)."""
+        return torch.stack([g(o.float()) for g, o in zip(self.G, omics)], dim=1)
+
+    def _pool(self, tokens, head, rho):
+        """(B, L, d) -> raw scores (B, 1, L), pooled embedding (B, d)  (models/mcat/mcat.py:105-109)."""
+        a = head.scores(tokens).transpose(1, 2)                       # (B, 1, L)
+        h = torch.bmm(torch.softmax(a, dim=2), tokens).squeeze(1)     # (B, d)
+        h = F.dropout(ops.linear(h, rho[0].weight, rho[0].bias, "relu"), rho[2].p, self.training)
+        return a, h
+
+    def _tail(self, h_coattn, g_bag):
+        path = self.path_transformer(h_coattn)
+        omic = self.omic_transformer(g_bag)
+        a_path, h_path = self._pool(path, self.path_attention_head, self.path_rho)
+        a_omic, h_omic = self._pool(omic, self.omic_attention_head, self.omic_rho)
+        h = self.fusion_layer(h_path, h_omic)
+        logits = ops.linear(h, self.classifier.weight, self.classifier.bias)   # (B, C)
+        hazards = torch.sigmoid(logits)
+        survs = torch.cumprod(1 - hazards, dim=1)
+        y = torch.softmax(logits, dim=1)
+        return hazards, survs, y, a_path, a_omic
+
+    # ---- window API
+    def forward_window(self, bags: BagBatch, omics: "List[torch.Tensor]", inference: bool = False):
+        """bags: raw patch features (total_rows, 1024) of the window; omics: per group (B, d_i).
+        Returns hazards, survs, Y (B, C) and {'coattn': [ (N, M_b) ] | None, 'path': (B,1,N), 'omic': (B,1,N)}."""
+        h_bags = self._patch_fc(bags)
+        g_bag = self._omic_fc(omics)
+        h_coattn, a_coattn = self._co_attend(g_bag, h_bags, inference)
+        hazards, survs, y, a_path, a_omic = self._tail(h_coattn, g_bag)
+        return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
+
+    def _forward_one(self, wsi, omics, inference):
+        """The reference's call: wsi (1,M,1024) or (M,1024); omics list of (1,d_i) or (d_i,)."""
+        x = wsi.squeeze(0) if wsi.dim() == 3 else wsi
+        if x.dtype != self.bag_dtype:
+            x = x.to(self.bag_dtype)
+        bags = BagBatch.from_list([x])
+        om = [o.reshape(1, -1) for o in omics]
+        hazards, survs, y, att = self.forward_window(bags, om, inference)
+        co = att["coattn"][0] if att["coattn"] is not None else None
+        return hazards, survs, y, {"coattn": co, "path": att["path"][0], "omic": att["omic"][0]}
+
+    def get_trainable_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+
+class MultimodalCoAttentionTransformer(_FusionModelBase):
+    """MCAT (models/mcat/mcat.py:12).  forward(wsi, omics, inference=False)."""
+
+    def __init__(self, omic_sizes: [], model_size: str = "medium", n_classes: int = 4, dropout: float = 0.25,
+                 fusion: str = "concat", device: str = "cpu", bag_dtype: torch.dtype = torch.float32):
+        super().__init__(omic_sizes, model_size, n_classes, dropout, fusion, device, bag_dtype)
+
+    def _make_co_attention(self, d):
+        return CoAttention(embed_dim=d, num_heads=1)
+
+    def _co_attend(self, g_bag, h_bags, inference):
+        return self.co_attention.forward_window(g_bag, h_bags, need_weights=inference)
+
+    def forward(self, wsi, omics, inference: bool = False):
+        return self._forward_one(wsi, omics, inference)
+
+
+class NarrowContextualAttentionGateTransformer(_FusionModelBase):
+    """NaCAGaT (models/nacagat/nacagat.py:9).  forward(wsi, omics): the map is always returned (:93)."""
+
+    def __init__(self, omic_sizes: [], model_size: str = "medium", n_classes: int = 4, dropout: float = 0.25,
+                 fusion: str = "concat", device: str = "cpu", bag_dtype: torch.dtype = torch.float32):
+        super().__init__(omic_sizes, model_size, n_classes, dropout, fusion, device, bag_dtype)
+
+    def _make_co_attention(self, d):
+        return PreGatingContextualAttention(embed_dim=d, num_heads=1)
+
+    def _co_attend(self, g_bag, h_bags, inference):
+        return self.co_attention.forward_window(g_bag, h_bags)
+
+    def forward(self, wsi, omics):
+        return self._forward_one(wsi, omics, True)

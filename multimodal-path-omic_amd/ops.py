@@ -170,3 +170,53 @@ class CoAttnMCATFn(torch.autograd.Function):
 def coattn_mcat(query, batch: BagBatch, in_w, in_b, out_w, out_b, need_weights: bool):
     """query (n_slides*n_q, E) -> (out (n_slides*n_q, E), ragged map or None)."""
     return CoAttnMCATFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, need_weights)
+
+
+# ------------------------------------------------------------------------------------ tail (6 x d tokens per slide)
+# The linears below run on the HIP fp32-MFMA GEMM; the element-wise glue between them is being
+# moved into fused HIP kernels family by family (K3..K6).
+import torch.nn.functional as F  # noqa: E402
+
+
+def gated_scores(x, wa, ba, wb, bb, wc, bc, drop_p: float):
+    """AttentionNetGated scores (models/blocks.py:42-47): x (..., L, D) -> (..., L, n_classes)."""
+    a = linear(x, wa, ba, "tanh")
+    b = linear(x, wb, bb, "sigmoid")
+    if drop_p > 0.0:
+        a = F.dropout(a, drop_p, True)
+        b = F.dropout(b, drop_p, True)
+    return linear(a * b, wc, bc)
+
+
+def contextual_gate(q, q_hat, cag):
+    """ContextualAttentionGate.forward (models/blocks.py:247-253) on (R, D) rows."""
+    g = F.elu(linear(q, cag.fc1[0].weight, cag.fc1[0].bias, "elu") + linear(q_hat, cag.fc2[0].weight, cag.fc2[0].bias, "elu"))
+    g = F.layer_norm(g, g.shape[-1:], cag.G[1].weight, cag.G[1].bias, cag.G[1].eps)
+    e = F.elu(linear(q_hat, cag.fc3[0].weight, cag.fc3[0].bias, "elu"))
+    e = F.layer_norm(e, e.shape[-1:], cag.E[1].weight, cag.E[1].bias, cag.E[1].eps)
+    return linear(g * e, cag.fc_c[0].weight, cag.fc_c[0].bias, "elu")
+
+
+def encoder_layer(x, layer, training: bool):
+    """One post-norm TransformerEncoderLayer on x (B, T, d) (torch/nn/modules/transformer.py:661)."""
+    sa = layer.self_attn
+    b, t, d = x.shape
+    h = sa.num_heads
+    p = layer.dropout.p if training else 0.0
+    qkv = linear(x, sa.in_proj_weight, sa.in_proj_bias).view(b, t, 3, h, d // h)
+    q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
+    s = torch.softmax(q @ k.transpose(-1, -2) / float(d // h) ** 0.5, dim=-1)
+    if p > 0.0:
+        s = F.dropout(s, p, True)
+    o = (s @ v).transpose(1, 2).reshape(b, t, d)
+    o = linear(o, sa.out_proj.weight, sa.out_proj.bias)
+    if p > 0.0:
+        o = F.dropout(o, p, True)
+    x = F.layer_norm(x + o, (d,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+    f = linear(x, layer.linear1.weight, layer.linear1.bias, "relu")
+    if p > 0.0:
+        f = F.dropout(f, p, True)
+    f = linear(f, layer.linear2.weight, layer.linear2.bias)
+    if p > 0.0:
+        f = F.dropout(f, p, True)
+    return F.layer_norm(x + f, (d,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
