@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p  # noqa: F401
 
 import torch
 
@@ -36,6 +36,13 @@ _SIGNATURES = {
                                         _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_nacagat_saved_floats": (c_size_t, [c_int, c_int, c_int]),
+    "mpo_nacagat_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "mpo_coattn_nacagat_forward": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
+                                           c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_coattn_nacagat_backward": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
+                                            c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P,
+                                            _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
 }
 
 

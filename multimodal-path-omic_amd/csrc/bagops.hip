@@ -1,0 +1,463 @@
+// Generic single-pass bag kernels + N x M map kernels: the building blocks of K2, NaCAGaT's
+// narrow-gated co-attention (models/blocks.py:114-206), in its first, modular form.
+//
+//   S[n][m] = (q~[n].k[m]) * (tanh(q)[n].tanh(k)[m] + 1) / 2,  A = softmax_m(S),  A_drop = dropout(A)
+//   ctx[n]  = sum_m A_drop[n][m] H[m]          (value projection folded out: A v = (A H) W_v^T + b_v sum_m A)
+//
+// Every long tensor (K = H W_k^T + b_k, TK = tanh K, H, and their gradients) is streamed exactly once
+// per kernel through the LDS tile image of coattn_tile.h; the coupling between them goes through
+// ragged N x M fp32 maps (24 bytes per patch, against 512-1024 bytes per patch of bag data):
+//   bag_rowdot   : map[n][m]  = sum_e X[m][e] r[n][e]                 (a = qs.K, g = tq.TK, dA = dctx.H)
+//   bag_colacc   : acc[n][e]  = sum_m W[n][m] X[m][e]   (split-M)     (ctx = A.H, dq~ = ds1.K, dtq = dg.TK)
+//   bag_outer    : dX[m][e]   = sum_n W1[n][m] Z1[n][e] + W2[n][m] Z2[n][e]   (dK, dTK, dH)
+//   map kernels  : gated softmax statistics / apply (+ dropout) / backward.
+// The same MFMA orientation rules as K1 apply (query index on the MFMA column).  A fully fused K2
+// (in-kernel K projection, one pass) is the planned successor; this form is parity-complete.
+#include "coattn_tile.h"
+#include "mpo_kernels.h"
+
+namespace {
+
+template <int E_, bool F32BAG>
+struct BagCfg {
+    static constexpr int NT = F32BAG ? 2 : 1;
+    static constexpr int WAVES = (F32BAG && E_ == 512) ? 2 : 4;
+    static constexpr int WAVE_LDS = NT * TileGeom<E_>::TILEB;
+    static constexpr int LDS_BYTES = WAVES * WAVE_LDS;
+};
+
+struct SplitGeom {
+    int row_begin, m_rows, r0, r1, n_my;
+};
+template <int WAVES>
+__device__ __forceinline__ SplitGeom split_geom(const int* cu, int b, int split, int splits, int wave) {
+    SplitGeom s;
+    s.row_begin = cu[b];
+    s.m_rows = cu[b + 1] - s.row_begin;
+    const int rps = ((s.m_rows + splits - 1) / splits + kTileRows - 1) / kTileRows * kTileRows;
+    s.r0 = split * rps;
+    s.r1 = min(s.m_rows, s.r0 + rps);
+    const int ntiles = s.r1 > s.r0 ? (s.r1 - s.r0 + kTileRows - 1) / kTileRows : 0;
+    s.n_my = wave < ntiles ? (ntiles - wave + WAVES - 1) / WAVES : 0;
+    return s;
+}
+
+// ------------------------------------------------------------------ (i) map[n][m] = alpha * X[m] . r[n]
+template <int E_, bool F32BAG>
+__global__ __launch_bounds__((BagCfg<E_, F32BAG>::WAVES * 64), 1)
+void bag_rowdot_kernel(const void* __restrict__ bag_, const int* __restrict__ cu, const float* __restrict__ r,
+                       float* __restrict__ map, float alpha, int n_q, int splits) {
+    using G = TileGeom<E_>;
+    using C = BagCfg<E_, F32BAG>;
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const SplitGeom sg = split_geom<C::WAVES>(cu, b, blockIdx.x, splits, wave);
+    char* thi = lds + wave * C::WAVE_LDS;
+    char* tlo = thi + (C::NT - 1) * G::TILEB;
+    const int q = lane & 15, g = lane >> 4;
+    bf16x8 rh[G::KS], rl[G::KS];
+    load_query_frags<E_>(r + (size_t)b * n_q * E_, n_q, lane, rh, rl);
+    float* mrow = map + (size_t)n_q * sg.row_begin + (size_t)q * sg.m_rows;
+    const char* slide = reinterpret_cast<const char*>(bag_) + (size_t)sg.row_begin * E_ * (F32BAG ? 4 : 2);
+    Stage<E_, F32BAG> st0, st1;
+    if (sg.n_my > 0) {
+        st0.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 0, lane);
+        if constexpr (F32BAG) st1.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 1, lane);
+    }
+    for (int it = 0; it < sg.n_my; ++it) {
+        const int trow = sg.r0 + kTileRows * (wave + it * C::WAVES);
+        const int nvalid = min(kTileRows, sg.r1 - trow);
+        st0.store(thi, tlo, 0, lane);
+        if constexpr (F32BAG) st1.store(thi, tlo, 1, lane);
+        if (it + 1 < sg.n_my) {
+            st0.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 0, lane);
+            if constexpr (F32BAG) st1.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 1, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        tile_dot_rows<E_, C::NT>(thi, tlo, rh, rl, s0, s1, lane);
+        if (q < n_q) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if (4 * g + rr < nvalid) mrow[trow + 4 * g + rr] = s0[rr] * alpha;
+                if (16 + 4 * g + rr < nvalid) mrow[trow + 16 + 4 * g + rr] = s1[rr] * alpha;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ (ii) part[n][e] = sum_m W[n][m] X[m][e]
+template <int E_, bool F32BAG>
+__global__ __launch_bounds__((BagCfg<E_, F32BAG>::WAVES * 64), 1)
+void bag_colacc_kernel(const void* __restrict__ bag_, const int* __restrict__ cu, const float* __restrict__ wmap,
+                       float* __restrict__ part, int n_q, int splits) {
+    using G = TileGeom<E_>;
+    using C = BagCfg<E_, F32BAG>;
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y, split = blockIdx.x;
+    const SplitGeom sg = split_geom<C::WAVES>(cu, b, split, splits, wave);
+    char* thi = lds + wave * C::WAVE_LDS;
+    char* tlo = thi + (C::NT - 1) * G::TILEB;
+    const int q = lane & 15, g = lane >> 4;
+    const float* wrow = wmap + (size_t)n_q * sg.row_begin + (size_t)(q < n_q ? q : 0) * sg.m_rows;
+    const char* slide = reinterpret_cast<const char*>(bag_) + (size_t)sg.row_begin * E_ * (F32BAG ? 4 : 2);
+    f32x4 acc[G::DT];
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Stage<E_, F32BAG> st0, st1;
+    if (sg.n_my > 0) {
+        st0.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 0, lane);
+        if constexpr (F32BAG) st1.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 1, lane);
+    }
+    for (int it = 0; it < sg.n_my; ++it) {
+        const int trow = sg.r0 + kTileRows * (wave + it * C::WAVES);
+        const int nvalid = min(kTileRows, sg.r1 - trow);
+        float w[8];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            w[rr] = (q < n_q && 4 * g + rr < nvalid) ? wrow[trow + 4 * g + rr] : 0.f;
+            w[4 + rr] = (q < n_q && 16 + 4 * g + rr < nvalid) ? wrow[trow + 16 + 4 * g + rr] : 0.f;
+        }
+        st0.store(thi, tlo, 0, lane);
+        if constexpr (F32BAG) st1.store(thi, tlo, 1, lane);
+        if (it + 1 < sg.n_my) {
+            st0.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 0, lane);
+            if constexpr (F32BAG) st1.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 1, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 wh, wl;
+        pack_hi_lo(w, wh, wl);
+        tile_accum_cols<E_, C::NT>(thi, tlo, wh, wl, acc, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        float* wq = reinterpret_cast<float*>(thi);
+#pragma unroll
+        for (int t = 0; t < G::DT; ++t) *reinterpret_cast<f32x4*>(wq + q * E_ + 16 * t + 4 * g) = acc[t];
+    }
+    __syncthreads();
+    const size_t pbase = (size_t)b * splits + split;
+    for (int idx = threadIdx.x; idx < n_q * E_; idx += C::WAVES * 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < C::WAVES; ++w) a += reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[idx];
+        part[pbase * n_q * E_ + idx] = a;
+    }
+}
+
+// ------------------------------------------------------------------ (iii) dX[m][e] = sum_n W1[n][m] Z1[n][e] + W2[n][m] Z2[n][e]
+// Output only (no bag input).  OUT_F32: dtype of dX.  w2/z2 may be null.
+template <int E_, bool OUT_F32>
+__global__ __launch_bounds__(256, 1)
+void bag_outer_kernel(const int* __restrict__ cu, const float* __restrict__ w1, const float* __restrict__ z1,
+                      const float* __restrict__ w2, const float* __restrict__ z2, void* __restrict__ dx_,
+                      int n_q, int splits) {
+    using G = TileGeom<E_>;
+    constexpr int EB = OUT_F32 ? 4 : 2;
+    constexpr int IMG = kTileRows * E_ * EB;
+    __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const SplitGeom sg = split_geom<4>(cu, b, blockIdx.x, splits, wave);
+    char* img = lds + wave * IMG;
+    const int c16 = lane & 15, g = lane >> 4;
+    const float* z1b = z1 + (size_t)b * n_q * E_;
+    const float* z2b = z2 ? z2 + (size_t)b * n_q * E_ : nullptr;
+    bf16x8 zh[G::DT], zl[G::DT];
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) {
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qq = 4 * g + j;
+            const int qc = qq < n_q ? qq : n_q - 1;
+            const float live = qq < n_q ? 1.0f : 0.0f;
+            z[j] = z1b[qc * E_ + 16 * t + c16] * live;
+            z[4 + j] = z2b ? z2b[qc * E_ + 16 * t + c16] * live : 0.f;
+        }
+        pack_hi_lo(z, zh[t], zl[t]);
+    }
+    const float* w1b = w1 + (size_t)n_q * sg.row_begin;
+    const float* w2b = w2 ? w2 + (size_t)n_q * sg.row_begin : nullptr;
+    char* dslide = reinterpret_cast<char*>(dx_) + (size_t)sg.row_begin * E_ * EB;
+    for (int it = 0; it < sg.n_my; ++it) {
+        const int trow = sg.r0 + kTileRows * (wave + it * 4);
+        const int nvalid = min(kTileRows, sg.r1 - trow);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int row = 16 * pt + c16;
+            const bool ok = row < nvalid;
+            float w[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = 4 * g + r;
+                const bool live = ok && qq < n_q;
+                w[r] = live ? w1b[(size_t)qq * sg.m_rows + trow + row] : 0.f;
+                w[4 + r] = (live && w2b) ? w2b[(size_t)qq * sg.m_rows + trow + row] : 0.f;
+            }
+            bf16x8 wh, wl;
+            pack_hi_lo(w, wh, wl);
+#pragma unroll
+            for (int t = 0; t < G::DT; ++t) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                o = mfma_bf16(zh[t], wh, o);
+                o = mfma_bf16(zh[t], wl, o);
+                o = mfma_bf16(zl[t], wh, o);
+                if constexpr (!OUT_F32) {
+                    bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    const int c = (2 * t + (g >> 1)) ^ ((row & 7) << 1);
+                    *reinterpret_cast<bf16x4*>(img + row * G::ROWB + (c << 4) + 8 * (g & 1)) = ob;
+                } else {
+                    const int c = (4 * t + g) ^ ((row & 7) << 1);
+                    *reinterpret_cast<f32x4*>(img + row * (E_ * 4) + (c << 4)) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CH_PER_ROW = E_ * EB / 16;
+        constexpr int NCH = kTileRows * CH_PER_ROW / 64;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = i * 64 + lane;
+            const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(img + r * (E_ * EB) + ((cc ^ ((r & 7) << 1)) << 4));
+            if (r < nvalid) *reinterpret_cast<f32x4*>(dslide + ((size_t)(trow + r) * CH_PER_ROW + cc) * 16) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ map kernels (one workgroup per (query, slide))
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// a: log2-unit half-logits (qs2.k), g: gate dot (tq.tk).  S2 = a (g + 1).
+// Writes lse2[b][q], the (post-dropout) map A_drop in place of `amap`, and asum[b][q] = sum_m A_drop.
+__global__ __launch_bounds__(256)
+void gated_softmax_fwd_kernel(const float* __restrict__ amap_a, const float* __restrict__ gmap, const int* __restrict__ cu,
+                              float* __restrict__ out_map, float* __restrict__ lse2, float* __restrict__ asum,
+                              int n_q, float drop_p, unsigned long long seed, unsigned long long offset) {
+    __shared__ float red[4];
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
+    const size_t base = (size_t)n_q * row_begin + (size_t)q * m_rows;
+    float mx = -INFINITY;
+    for (int m = threadIdx.x; m < m_rows; m += 256) mx = fmaxf(mx, amap_a[base + m] * (gmap[base + m] + 1.0f));
+    mx = block_max(mx, red);
+    float l = 0.f;
+    for (int m = threadIdx.x; m < m_rows; m += 256)
+        l += __builtin_amdgcn_exp2f(amap_a[base + m] * (gmap[base + m] + 1.0f) - mx);
+    l = block_sum(l, red);
+    const float lse = mx + __builtin_amdgcn_logf(l);
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    float s = 0.f;
+    for (int m = threadIdx.x; m < m_rows; m += 256) {
+        float v = __builtin_amdgcn_exp2f(amap_a[base + m] * (gmap[base + m] + 1.0f) - lse);
+        if (drop_p > 0.f) v *= dropout_keep(seed, offset, base + m, drop_p, inv_keep);
+        out_map[base + m] = v;
+        s += v;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        lse2[(size_t)b * n_q + q] = lse;
+        asum[(size_t)b * n_q + q] = s;
+    }
+}
+
+// Backward of the gated softmax.  da_map holds dctx.H (from bag_rowdot) on entry; d_ext (nullable) is the
+// gradient arriving on the returned (post-dropout) map; dasum[b][q] the gradient of the row sums.
+// On exit: ds1_map[n][m] = dS (g+1)/2 (natural units, for q~.k) and dg_map[n][m] = dS * s1/2.
+__global__ __launch_bounds__(256)
+void gated_softmax_bwd_kernel(const float* __restrict__ amap_a, const float* __restrict__ gmap, const int* __restrict__ cu,
+                              const float* __restrict__ lse2, const float* __restrict__ dasum,
+                              const float* __restrict__ d_ext, float* __restrict__ da_map /* in: dctx.H, out: ds1 */,
+                              float* __restrict__ dg_map, int n_q, float drop_p, unsigned long long seed,
+                              unsigned long long offset) {
+    __shared__ float red[4];
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
+    const size_t base = (size_t)n_q * row_begin + (size_t)q * m_rows;
+    const float lse = lse2[(size_t)b * n_q + q];
+    const float das = dasum[(size_t)b * n_q + q];
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    float delta = 0.f;
+    for (int m = threadIdx.x; m < m_rows; m += 256) {
+        const float a = __builtin_amdgcn_exp2f(amap_a[base + m] * (gmap[base + m] + 1.0f) - lse);
+        const float ks = drop_p > 0.f ? dropout_keep(seed, offset, base + m, drop_p, inv_keep) : 1.0f;
+        float d = da_map[base + m] + das;
+        if (d_ext) d += d_ext[base + m];
+        delta += a * ks * d;
+    }
+    delta = block_sum(delta, red);
+    for (int m = threadIdx.x; m < m_rows; m += 256) {
+        const float ah = amap_a[base + m], gg = gmap[base + m];
+        const float a = __builtin_amdgcn_exp2f(ah * (gg + 1.0f) - lse);
+        const float ks = drop_p > 0.f ? dropout_keep(seed, offset, base + m, drop_p, inv_keep) : 1.0f;
+        float d = da_map[base + m] + das;
+        if (d_ext) d += d_ext[base + m];
+        const float ds = a * (ks * d - delta);
+        da_map[base + m] = ds * (gg + 1.0f) * 0.5f;      // d/d(q~.k)
+        dg_map[base + m] = ds * ah * kLn2;               // dS * s1/2 with s1/2 = ah / log2(e)
+    }
+}
+
+// elementwise over a bag-shaped tensor: y = tanh(x)  /  dx += dy * (1 - y^2)
+template <typename T>
+__global__ void bag_tanh_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = (float)x[i];
+        const float e = __builtin_amdgcn_exp2f(v * (2.0f * kLog2e));
+        y[i] = (T)(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f));
+    }
+}
+template <typename T>
+__global__ void bag_tanh_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = (float)y[i];
+        dx[i] = (T)((float)dx[i] + (float)dy[i] * (1.0f - t * t));
+    }
+}
+
+// q-side preparation: q [R][E] -> qt = q / sqrt(E), qs2 = qt * log2e / 2, tq = tanh(q)
+__global__ void qprep_kernel(const float* __restrict__ q, float* __restrict__ qt, float* __restrict__ qs2,
+                             float* __restrict__ tq, int n, float c_nat) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = q[i];
+    qt[i] = v * c_nat;
+    qs2[i] = v * c_nat * (0.5f * kLog2e);
+    tq[i] = tanhf(v);
+}
+// dq = dqt * c_nat + dtq * (1 - tq^2) [+ d_ext]
+__global__ void qprep_bwd_kernel(const float* __restrict__ dqt, const float* __restrict__ dtq, const float* __restrict__ tq,
+                                 const float* __restrict__ d_ext, float* __restrict__ dq, int n, float c_nat) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = tq[i];
+    dq[i] = dqt[i] * c_nat + dtq[i] * (1.0f - t * t) + (d_ext ? d_ext[i] : 0.f);
+}
+
+// y[r][:] += s[r] * b[:]      (value-bias term  b_v * sum_m A_drop)
+__global__ void row_scaled_bias_kernel(float* __restrict__ y, const float* __restrict__ s, const float* __restrict__ bias,
+                                       int rows, int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    y[i] += s[i / cols] * bias[i % cols];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- host launchers
+#define MPO_E_SWITCH(embed, CALL)                                                     \
+    switch (embed) {                                                                  \
+        case 128: { constexpr int EV = 128; CALL; } break;                            \
+        case 256: { constexpr int EV = 256; CALL; } break;                            \
+        default: mpo_set_error("bag kernels: embed_dim %d not in {128,256}", embed); return 1; \
+    }
+
+int mpo_launch_bag_rowdot(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* r,
+                          float* map, float alpha, int n_q, int splits, hipStream_t stream) {
+    dim3 grid(splits, n_slides);
+    if (bag_f32) {
+        MPO_E_SWITCH(embed, (bag_rowdot_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, r, map, alpha, n_q, splits)))
+    } else {
+        MPO_E_SWITCH(embed, (bag_rowdot_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, r, map, alpha, n_q, splits)))
+    }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_bag_colacc(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* wmap,
+                          float* part, int n_q, int splits, hipStream_t stream) {
+    dim3 grid(splits, n_slides);
+    if (bag_f32) {
+        MPO_E_SWITCH(embed, (bag_colacc_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, wmap, part, n_q, splits)))
+    } else {
+        MPO_E_SWITCH(embed, (bag_colacc_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, wmap, part, n_q, splits)))
+    }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_bag_outer(const int* cu, int n_slides, int embed, const float* w1, const float* z1, const float* w2,
+                         const float* z2, void* dx, int out_f32, int n_q, int splits, hipStream_t stream) {
+    dim3 grid(splits, n_slides);
+    if (out_f32) {
+        MPO_E_SWITCH(embed, (bag_outer_kernel<EV, true><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, splits)))
+    } else {
+        MPO_E_SWITCH(embed, (bag_outer_kernel<EV, false><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, splits)))
+    }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_gated_softmax_fwd(const float* amap_a, const float* gmap, const int* cu, float* out_map, float* lse2,
+                                 float* asum, int n_slides, int n_q, float drop_p, unsigned long long seed,
+                                 unsigned long long offset, hipStream_t stream) {
+    gated_softmax_fwd_kernel<<<dim3(n_q, n_slides), 256, 0, stream>>>(amap_a, gmap, cu, out_map, lse2, asum, n_q, drop_p, seed, offset);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_gated_softmax_bwd(const float* amap_a, const float* gmap, const int* cu, const float* lse2,
+                                 const float* dasum, const float* d_ext, float* da_map, float* dg_map, int n_slides,
+                                 int n_q, float drop_p, unsigned long long seed, unsigned long long offset,
+                                 hipStream_t stream) {
+    gated_softmax_bwd_kernel<<<dim3(n_q, n_slides), 256, 0, stream>>>(amap_a, gmap, cu, lse2, dasum, d_ext, da_map, dg_map, n_q,
+                                                                      drop_p, seed, offset);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_bag_tanh_fwd(const void* x, void* y, size_t n, int f32, hipStream_t stream) {
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (f32) bag_tanh_fwd_kernel<float><<<blocks, 256, 0, stream>>>((const float*)x, (float*)y, n);
+    else bag_tanh_fwd_kernel<__bf16><<<blocks, 256, 0, stream>>>((const __bf16*)x, (__bf16*)y, n);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_bag_tanh_bwd(const void* y, const void* dy, void* dx, size_t n, int f32, hipStream_t stream) {
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (f32) bag_tanh_bwd_kernel<float><<<blocks, 256, 0, stream>>>((const float*)y, (const float*)dy, (float*)dx, n);
+    else bag_tanh_bwd_kernel<__bf16><<<blocks, 256, 0, stream>>>((const __bf16*)y, (const __bf16*)dy, (__bf16*)dx, n);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_qprep(const float* q, float* qt, float* qs2, float* tq, int n, float c_nat, hipStream_t stream) {
+    qprep_kernel<<<(n + 255) / 256, 256, 0, stream>>>(q, qt, qs2, tq, n, c_nat);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_qprep_bwd(const float* dqt, const float* dtq, const float* tq, const float* d_ext, float* dq, int n,
+                         float c_nat, hipStream_t stream) {
+    qprep_bwd_kernel<<<(n + 255) / 256, 256, 0, stream>>>(dqt, dtq, tq, d_ext, dq, n, c_nat);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_row_scaled_bias(float* y, const float* s, const float* bias, int rows, int cols, hipStream_t stream) {
+    row_scaled_bias_kernel<<<(rows * cols + 255) / 256, 256, 0, stream>>>(y, s, bias, rows, cols);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}

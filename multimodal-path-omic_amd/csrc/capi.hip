@@ -180,6 +180,135 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- K2
+// saved layout (floats), R = n_slides * n_q:  qt | qs2 | tq | ctx | attn  (each [R,E])  | lse2 [R] | asum [R]
+size_t mpo_nacagat_saved_floats(int n_slides, int n_q, int embed) {
+    const size_t R = (size_t)n_slides * n_q;
+    return 5 * R * embed + 2 * R;
+}
+size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_rows, int total_rows) {
+    const size_t R = (size_t)n_slides * n_q;
+    const size_t splits = mpo_coattn_splits(n_slides, max_rows);
+    size_t b = 0;
+    for (int i = 0; i < 6; ++i) b = arena_need(b, R * embed);
+    b = arena_need(b, R);
+    b = arena_need(b, (size_t)n_slides * splits * n_q * embed);
+    b = arena_need(b, (size_t)n_q * total_rows);
+    b = arena_need(b, (size_t)n_q * total_rows);
+    return b + 256;
+}
+
+int mpo_coattn_nacagat_forward(const void* kbag, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,
+                               int total_rows, int max_rows, const float* query, int n_q, int embed,
+                               const float* in_w, const float* in_b, const float* out_w, const float* out_b,
+                               float drop_p, uint64_t seed, uint64_t offset,
+                               void* tkbag, float* q_proj, float* out, float* attn_map, float* score_maps,
+                               float* saved, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
+    MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
+    MPO_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention dropout p must be in [0,1) (got %f)", (double)drop_p);
+    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32;
+    const int splits = mpo_coattn_splits(n_slides, max_rows);
+    Arena ws(workspace, workspace_bytes);
+    float* part = ws.floats((size_t)n_slides * splits * n_q * E);
+    MPO_CHECK(part, "nacagat forward: workspace too small (%zu bytes)", workspace_bytes);
+    float* qt = saved;
+    float* qs2 = qt + (size_t)R * E;
+    float* tq = qs2 + (size_t)R * E;
+    float* ctx = tq + (size_t)R * E;
+    float* attn = ctx + (size_t)R * E;
+    float* lse2 = attn + (size_t)R * E;
+    float* asum = lse2 + R;
+    float* a_map = score_maps;
+    float* g_map = score_maps + (size_t)n_q * total_rows;
+    int rc;
+    // q = query W_q^T + b_q  (returned: the reference hands it to the CAG, models/blocks.py:110,206)
+    if ((rc = mpo_linear_fwd(query, in_w, in_b, q_proj, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
+    if ((rc = mpo_launch_qprep(q_proj, qt, qs2, tq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
+    if ((rc = mpo_launch_bag_tanh_fwd(kbag, tkbag, (size_t)total_rows * E, f32, stream))) return rc;
+    if ((rc = mpo_launch_bag_rowdot(kbag, f32, cu_rows, n_slides, E, qs2, a_map, 1.0f, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_rowdot(tkbag, f32, cu_rows, n_slides, E, tq, g_map, 1.0f, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_gated_softmax_fwd(a_map, g_map, cu_rows, attn_map, lse2, asum, n_slides, n_q, drop_p, seed, offset, stream))) return rc;
+    if ((rc = mpo_launch_bag_colacc(hbag, f32, cu_rows, n_slides, E, attn_map, part, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_coattn_bwd_reduce(part, ctx, n_slides, n_q, E, splits, stream))) return rc;
+    // attn = ctx W_v^T + (sum_m A_drop) b_v ;  out = attn W_o^T + b_o
+    if ((rc = mpo_linear_fwd(ctx, in_w + (size_t)2 * E * E, nullptr, attn, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
+    if ((rc = mpo_launch_row_scaled_bias(attn, asum, in_b + 2 * E, R, E, stream))) return rc;
+    if ((rc = mpo_linear_fwd(attn, out_w, out_b, out, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
+    return 0;
+}
+
+int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, const void* hbag, int bag_dtype,
+                                const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
+                                const float* query, int n_q, int embed, const float* in_w, const float* in_b,
+                                const float* out_w, float drop_p, uint64_t seed, uint64_t offset,
+                                const float* saved, const float* score_maps, const float* attn_map,
+                                const float* d_out, const float* d_attn_map, const float* d_q_proj,
+                                float* d_query, void* d_kbag, void* d_tk_scratch, void* d_hbag,
+                                float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
+                                void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
+    MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
+    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32;
+    const int splits = mpo_coattn_splits(n_slides, max_rows);
+    Arena ws(workspace, workspace_bytes);
+    float* dattn = ws.floats((size_t)R * E);
+    float* dctx = ws.floats((size_t)R * E);
+    float* dqt = ws.floats((size_t)R * E);
+    float* dtq = ws.floats((size_t)R * E);
+    float* dq = ws.floats((size_t)R * E);
+    float* spare = ws.floats((size_t)R * E);
+    float* dasum = ws.floats(R);
+    float* part = ws.floats((size_t)n_slides * splits * n_q * E);
+    float* ds1_map = ws.floats((size_t)n_q * total_rows);
+    float* dg_map = ws.floats((size_t)n_q * total_rows);
+    MPO_CHECK(dattn && dctx && dqt && dtq && dq && spare && dasum && part && ds1_map && dg_map,
+              "nacagat backward: workspace too small (%zu bytes)", workspace_bytes);
+    const float* qt = saved;
+    const float* qs2 = qt + (size_t)R * E;
+    const float* tq = qs2 + (size_t)R * E;
+    const float* ctx = tq + (size_t)R * E;
+    const float* attn = ctx + (size_t)R * E;
+    const float* lse2 = attn + (size_t)R * E;
+    const float* asum = lse2 + R;
+    const float* a_map = score_maps;
+    const float* g_map = score_maps + (size_t)n_q * total_rows;
+    const float* w_q = in_w;
+    const float* w_v = in_w + (size_t)2 * E * E;
+    const float* b_v = in_b + 2 * E;
+    (void)qs2;
+    int rc;
+    // out = attn W_o^T + b_o
+    if ((rc = mpo_linear_bwd_input(d_out, out_w, dattn, R, E, E, 1.0f, 0, stream))) return rc;
+    if ((rc = mpo_linear_bwd_weight(d_out, attn, d_out_w, d_out_b, R, E, E, 1.0f, stream))) return rc;
+    // attn = ctx W_v^T + asum (x) b_v
+    if ((rc = mpo_linear_bwd_input(dattn, w_v, dctx, R, E, E, 1.0f, 0, stream))) return rc;
+    if ((rc = mpo_linear_bwd_weight(dattn, ctx, d_in_w + (size_t)2 * E * E, nullptr, R, E, E, 1.0f, stream))) return rc;
+    if ((rc = mpo_linear_bwd_weight(asum, dattn, d_in_b + 2 * E, nullptr, R, E, 1, 1.0f, stream))) return rc;   // db_v = asum^T dattn
+    if ((rc = mpo_linear_fwd(dattn, b_v, nullptr, dasum, R, E, 1, 1.0f, MPO_ACT_NONE, stream))) return rc;        // dasum = dattn b_v
+    // map side
+    if ((rc = mpo_launch_bag_rowdot(hbag, f32, cu_rows, n_slides, E, dctx, ds1_map, 1.0f, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_gated_softmax_bwd(a_map, g_map, cu_rows, lse2, dasum, d_attn_map, ds1_map, dg_map, n_slides, n_q,
+                                           drop_p, seed, offset, stream))) return rc;
+    // query side: dq~ = ds1 K, dtq = dg TK
+    if ((rc = mpo_launch_bag_colacc(kbag, f32, cu_rows, n_slides, E, ds1_map, part, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_coattn_bwd_reduce(part, dqt, n_slides, n_q, E, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_colacc(tkbag, f32, cu_rows, n_slides, E, dg_map, part, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_coattn_bwd_reduce(part, dtq, n_slides, n_q, E, splits, stream))) return rc;
+    if ((rc = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
+    if ((rc = mpo_linear_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0, stream))) return rc;
+    if ((rc = mpo_linear_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f, stream))) return rc;
+    // bag side: dK = ds1^T q~ + (dg^T tq) * (1 - TK^2),  dH = A_drop^T dctx
+    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, ds1_map, qt, nullptr, nullptr, d_kbag, f32, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, dg_map, tq, nullptr, nullptr, d_tk_scratch, f32, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_tanh_bwd(tkbag, d_tk_scratch, d_kbag, (size_t)total_rows * E, f32, stream))) return rc;
+    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, attn_map, dctx, nullptr, nullptr, d_hbag, f32, n_q, splits, stream))) return rc;
+    // the key slice of the packed in-projection belongs to the caller's K = H W_k^T + b_k
+    MPO_HIP(hipMemsetAsync(d_in_w + (size_t)E * E, 0, (size_t)E * E * sizeof(float), stream));
+    MPO_HIP(hipMemsetAsync(d_in_b + E, 0, (size_t)E * sizeof(float), stream));
+    return 0;
+}
+
 int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
                            const float* qk2, float* part_ml, float* part_ctx, float* raw_logits, int n_q, int splits,
                            mpo_stream_t stream) {

@@ -69,3 +69,24 @@ int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides
 int mpo_launch_rowdot(const float* a, const float* b, float* out, int rows, int cols, hipStream_t stream);
 int mpo_launch_map_rowdot(const float* a_map, const float* da_map, const int* cu, float* delta, int n_slides, int n_q,
                           int accumulate, hipStream_t stream);
+
+// ---- generic bag / map kernels (bagops.hip): the modular form of K2
+int mpo_launch_bag_rowdot(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* r,
+                          float* map, float alpha, int n_q, int splits, hipStream_t stream);
+int mpo_launch_bag_colacc(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* wmap,
+                          float* part, int n_q, int splits, hipStream_t stream);
+int mpo_launch_bag_outer(const int* cu, int n_slides, int embed, const float* w1, const float* z1, const float* w2,
+                         const float* z2, void* dx, int out_f32, int n_q, int splits, hipStream_t stream);
+int mpo_launch_gated_softmax_fwd(const float* amap_a, const float* gmap, const int* cu, float* out_map, float* lse2,
+                                 float* asum, int n_slides, int n_q, float drop_p, unsigned long long seed,
+                                 unsigned long long offset, hipStream_t stream);
+int mpo_launch_gated_softmax_bwd(const float* amap_a, const float* gmap, const int* cu, const float* lse2,
+                                 const float* dasum, const float* d_ext, float* da_map, float* dg_map, int n_slides,
+                                 int n_q, float drop_p, unsigned long long seed, unsigned long long offset,
+                                 hipStream_t stream);
+int mpo_launch_bag_tanh_fwd(const void* x, void* y, size_t n, int f32, hipStream_t stream);
+int mpo_launch_bag_tanh_bwd(const void* y, const void* dy, void* dx, size_t n, int f32, hipStream_t stream);
+int mpo_launch_qprep(const float* q, float* qt, float* qs2, float* tq, int n, float c_nat, hipStream_t stream);
+int mpo_launch_qprep_bwd(const float* dqt, const float* dtq, const float* tq, const float* d_ext, float* dq, int n,
+                         float c_nat, hipStream_t stream);
+int mpo_launch_row_scaled_bias(float* y, const float* s, const float* bias, int rows, int cols, hipStream_t stream);

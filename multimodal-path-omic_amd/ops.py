@@ -220,3 +220,88 @@ def encoder_layer(x, layer, training: bool):
     if p > 0.0:
         f = F.dropout(f, p, True)
     return F.layer_norm(x + f, (d,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+
+
+# ------------------------------------------------------------------------------------ K2
+_rng_calls = 0
+
+
+def next_dropout_stream(n_elements: int):
+    """(seed, offset) for one dropout mask of n_elements: Philox counter space is carved sequentially per
+    process, the seed follows torch.initial_seed() (so torch.manual_seed(rank-dependent) de-correlates ranks)."""
+    global _rng_calls
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    offset = _rng_calls
+    _rng_calls += (n_elements + 3) // 4 + 1
+    return seed, offset
+
+
+class CoAttnNaCAGaTFn(torch.autograd.Function):
+    """NaCAGaT narrow-gated attention core over a ragged window (models/blocks.py:114-206).
+    Returns (q_proj, attn_out, post-dropout map).  K = H W_k^T + b_k is a plain GEMM done here with
+    torch (hipBLASLt) in the bag's dtype, like the model's patch layer; everything else is HIP."""
+
+    @staticmethod
+    def forward(ctx, query, bag_data, in_w, in_b, out_w, out_b, batch: BagBatch, drop_p: float):
+        lib = L.lib()
+        n_slides = batch.n_slides
+        R, E = query.shape
+        n_q = R // n_slides
+        dev, T = query.device, batch.total_rows
+        query = query.contiguous()
+        dt = bag_data.dtype
+        kbag = F.linear(bag_data, in_w[E:2 * E].to(dt), in_b[E:2 * E].to(dt))
+        tkbag = torch.empty_like(kbag)
+        q_proj = torch.empty(R, E, device=dev, dtype=torch.float32)
+        out = torch.empty(R, E, device=dev, dtype=torch.float32)
+        amap = torch.empty(n_q * T, device=dev, dtype=torch.float32)
+        score_maps = torch.empty(2 * n_q * T, device=dev, dtype=torch.float32)
+        saved = torch.empty(lib.mpo_nacagat_saved_floats(n_slides, n_q, E), device=dev, dtype=torch.float32)
+        ws = _workspace(lib.mpo_nacagat_workspace_bytes(n_slides, n_q, E, batch.max_rows, T), dev)
+        seed, offset = next_dropout_stream(n_q * T) if drop_p > 0 else (0, 0)
+        L.check(lib.mpo_coattn_nacagat_forward(
+            L.ptr(kbag), L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, T, batch.max_rows,
+            L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), L.ptr(out_b), float(drop_p), seed, offset,
+            L.ptr(tkbag), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
+            L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_forward")
+        ctx.save_for_backward(query, bag_data, kbag, tkbag, in_w, in_b, out_w, saved, score_maps, amap)
+        ctx.batch, ctx.n_q, ctx.drop = batch, n_q, (float(drop_p), seed, offset)
+        return q_proj, out, amap
+
+    @staticmethod
+    def backward(ctx, d_qproj, d_out, d_map):
+        lib = L.lib()
+        query, bag_data, kbag, tkbag, in_w, in_b, out_w, saved, score_maps, amap = ctx.saved_tensors
+        batch, n_q = ctx.batch, ctx.n_q
+        drop_p, seed, offset = ctx.drop
+        R, E = query.shape
+        dev, T = query.device, batch.total_rows
+        d_out = d_out.contiguous() if d_out is not None else torch.zeros(R, E, device=dev)
+        d_qproj = d_qproj.contiguous() if d_qproj is not None else None
+        d_map = d_map.contiguous() if d_map is not None else None
+        d_query = torch.empty_like(query)
+        d_k = torch.empty_like(kbag)
+        d_tk = torch.empty_like(kbag)
+        d_h = torch.empty_like(bag_data)
+        d_in_w = torch.empty_like(in_w)
+        d_in_b = torch.empty(3 * E, device=dev, dtype=torch.float32)
+        d_out_w = torch.empty_like(out_w)
+        d_out_b = torch.empty(E, device=dev, dtype=torch.float32)
+        ws = _workspace(lib.mpo_nacagat_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows, T), dev)
+        L.check(lib.mpo_coattn_nacagat_backward(
+            L.ptr(kbag), L.ptr(tkbag), L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
+            batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
+            L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
+            L.ptr(d_query), L.ptr(d_k), L.ptr(d_tk), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
+            L.ptr(d_out_b), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
+        # back through the caller-side GEMM  K = H W_k^T + b_k
+        dt = bag_data.dtype
+        d_h = torch.addmm(d_h, d_k, in_w[E:2 * E].to(dt))
+        d_in_w[E:2 * E] = torch.mm(d_k.t(), bag_data).float()
+        d_in_b[E:2 * E] = d_k.float().sum(0)
+        return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None
+
+
+def coattn_nacagat(query, batch: BagBatch, in_w, in_b, out_w, out_b, drop_p: float):
+    """query (n_slides*n_q, E) -> (q_proj, attn_out (n_slides*n_q, E), ragged post-dropout map)."""
+    return CoAttnNaCAGaTFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, drop_p)

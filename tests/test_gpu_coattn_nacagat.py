@@ -1,0 +1,120 @@
+"""GPU parity of K2 (NaCAGaT narrow-gated co-attention + CAG) against the oracle and the reference's
+golden vectors, including a gradient pushed into the attention map ('cesar' loss) and the
+training-mode attention-weight dropout (the kernel's own mask is replayed through the oracle)."""
+import pytest
+import torch
+
+import cases as C
+from multimodal_path_omic_amd import synthetic as syn
+from multimodal_path_omic_amd.blocks import ContextualAttentionGate, PreGatingContextualAttention
+from oracle import mpo_oracle as O
+
+pytestmark = pytest.mark.gpu
+sub = syn.subsample
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def make_module(seed, gain, dev):
+    sd = syn.fill_state_dict(C.NACAGAT_COATTN_SHAPES, seed, gain)
+    mod = PreGatingContextualAttention(embed_dim=C.E, num_heads=1)
+    mod.load_state_dict({k[len("co_attention."):]: v for k, v in sd.items()}, strict=True)
+    return mod.to(dev), {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+
+def oracle_grads(loss, named):
+    gs = torch.autograd.grad(loss, [t for _, t in named], allow_unused=True, retain_graph=True)
+    return {n: (torch.zeros_like(t) if g is None else g) for (n, t), g in zip(named, gs)}
+
+
+def test_cag_matches_golden(dev, golden):
+    g = golden("cag")
+    sd = syn.fill_state_dict(C.CAG_SHAPES, 500)
+    mod = ContextualAttentionGate(dim=C.E, hidden_dim=C.E)
+    mod.load_state_dict({k[len("co_attention.CAG."):]: v for k, v in sd.items()}, strict=True)
+    mod.to(dev)
+    q, qh, probe = C.cag_inputs()
+    qd, qhd = q.to(dev).requires_grad_(True), qh.to(dev).requires_grad_(True)
+    c = mod(qd, qhd)
+    assert relerr(c, g["C"]) < 1e-4
+    params = dict(mod.named_parameters())
+    names = ["Q", "Q_hat"] + list(sd)
+    tensors = [qd, qhd] + [params[k[len("co_attention.CAG."):]] for k in sd]
+    for n, gr in zip(names, torch.autograd.grad((c * probe.to(dev)).sum(), tensors)):
+        ref = g["grad/" + n]
+        got = gr if gr.numel() <= 4096 else sub(gr)
+        assert relerr(got, ref) < 1e-3, n
+
+
+@pytest.mark.parametrize("case", list(C.NACAGAT_CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nacagat_forward_backward(dev, golden, case, dtype):
+    m, gain, seed = C.NACAGAT_CASES[case]
+    mod, p = make_module(seed, gain, dev)
+    mod.eval()
+    q, bag, p_out, p_a = C.coattn_inputs(m, seed + 1)
+    bag_in = bag.to(dtype)
+    qo = q.clone().requires_grad_(True)
+    bo = bag_in.float().clone().requires_grad_(True)
+    out_o, a_o = O.pregating_contextual_attention(qo, bo, p)
+    named = [("query", qo), ("bag", bo)] + list(p.items())
+    g1_o = oracle_grads((out_o * p_out).sum() + (a_o * p_a).sum(), named)
+
+    qd = q.to(dev).requires_grad_(True)
+    bd = bag_in.to(dev).requires_grad_(True)
+    out, a = mod(query=qd, key=bd, value=bd)
+    assert a.shape == (C.N_OMIC, m)
+    f32 = dtype == torch.float32
+    # bf16 mode stores K = H W_k^T + b_k and tanh(K) in bf16 (storage of an intermediate): looser bars
+    assert relerr(out, out_o) < (2e-4 if f32 else 2e-2), relerr(out, out_o)
+    rel_a = ((a.detach().cpu() - a_o.detach()).abs() / a_o.detach().clamp_min(1e-30)).max().item()
+    assert rel_a < (1e-3 if f32 else 1.5e-1), rel_a
+    torch.testing.assert_close(a.sum(1).cpu(), torch.ones(C.N_OMIC), rtol=1e-4, atol=1e-4)
+    params = dict(mod.named_parameters())
+    tensors = [qd, bd] + [params[k[len("co_attention."):]] for k in p]
+    names = ["query", "bag"] + list(p)
+    gs = torch.autograd.grad((out * p_out.to(dev)).sum() + (a * p_a.to(dev)).sum(), tensors)
+    for n, gr in zip(names, gs):
+        tol = 2e-3 if f32 else 6e-2
+        e = relerr(gr, g1_o[n])
+        assert e < tol, (n, e)
+    if f32:
+        g = golden("coattn_nacagat")
+        assert relerr(out, g[f"{case}/out"]) < 1e-3
+        ga = g[f"{case}/A_sub"]
+        assert ((sub(a).cpu() - ga).abs() / ga.clamp_min(1e-30)).max().item() < 2e-3
+        for n, gr in zip(names, gs):
+            ref = g[f"{case}/grad1/{n}"]
+            assert relerr(sub(gr), ref) < 3e-3, (n, relerr(sub(gr), ref))
+
+
+def test_nacagat_training_dropout_replays_through_oracle(dev):
+    """Training mode: the returned map is post-dropout (models/blocks.py:189-190,206).  The mask is
+    recovered from the map (A > 0 everywhere before dropout) and replayed through the oracle."""
+    m, gain, seed = 3000, 1.0, 909
+    mod, p = make_module(seed, gain, dev)
+    mod.train()
+    q, bag, p_out, p_a = C.coattn_inputs(m, seed + 1)
+    qd = q.to(dev).requires_grad_(True)
+    bd = bag.to(dev).requires_grad_(True)
+    out, a = mod(query=qd, key=bd, value=bd)
+    keep = (a.detach().cpu() > 0).float() / 0.75
+    frac = float((keep > 0).float().mean())
+    assert abs(frac - 0.75) < 0.02, frac                              # p = 0.25 hard-wired default
+    qo, bo = q.clone().requires_grad_(True), bag.clone().requires_grad_(True)
+    out_o, a_o = O.pregating_contextual_attention(qo, bo, p, keep=keep)
+    assert relerr(out, out_o) < 2e-4
+    assert relerr(a, a_o) < 1e-3
+    named = [("query", qo), ("bag", bo)] + list(p.items())
+    g_o = oracle_grads((out_o * p_out).sum() + (a_o * p_a).sum(), named)
+    params = dict(mod.named_parameters())
+    tensors = [qd, bd] + [params[k[len("co_attention."):]] for k in p]
+    gs = torch.autograd.grad((out * p_out.to(dev)).sum() + (a * p_a.to(dev)).sum(), tensors)
+    for (n, _), gr in zip(named, gs):
+        assert relerr(gr, g_o[n]) < 2e-3, (n, relerr(gr, g_o[n]))
+    # a second call draws a different mask
+    _, a2 = mod(query=qd, key=bd, value=bd)
+    assert not torch.equal(a2 > 0, a > 0)

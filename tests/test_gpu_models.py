@@ -61,7 +61,7 @@ def test_model_matches_reference_golden(dev, golden, case):
     for n, p in model.named_parameters():
         ref = g[f"{case}/grad/{n}"]
         got = sub(p.grad if p.grad is not None else torch.zeros_like(p), 256).cpu()
-        scale = max(float(ref.abs().max()), 1e-6)
+        scale = max(float(ref.abs().max()), 1e-5)      # shift-invariant biases have ~1e-8 'gradients'
         assert float((got - ref).abs().max()) / scale < 5e-3, (n, float((got - ref).abs().max()) / scale)
 
 
