@@ -81,23 +81,25 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
 /* ---- K2: NaCAGaT narrow-gated co-attention core = models/blocks.py:114-206 (heads = 1):
  *   S = (q/sqrt(E)) k^T * (tanh(q) tanh(k)^T + 1)/2,  A = softmax(S),  A_drop = dropout(A, p) in training,
  *   out = (A_drop v) W_o^T + b_o,  returns (q, out, A_drop)  -- the map is post-dropout, as in the reference.
- * The caller supplies kbag = H W_k^T + b_k (bag dtype; a plain GEMM it owns, like self.H) and hbag = H;
- * the value projection is folded out.  tkbag (out) receives tanh(kbag) and must be kept for backward.
+ * The caller supplies kbag = H W_k^T + b_k (a plain GEMM it owns, like self.H; dtype k_dtype) and hbag = H;
+ * the value projection is folded out.  tkbag (out, k_dtype) receives tanh(kbag) and is kept for backward.
+ * k_dtype should be MPO_F32 even for a bf16 bag: the gate multiplies rounding errors of k (dS = (g+1) da),
+ * so k is an intermediate that must not be stored in bf16 (hard part 4).
  *   score_maps  2 * n_q * total_rows floats (kept for backward);  attn_map  n_q * total_rows floats (output)
  *   seed/offset Philox counter of the attention-weight dropout; pass the same pair to backward.
  * Backward takes gradients on all three returns (d_out, d_attn_map nullable, d_q_proj nullable) and emits
- * d_query, d_kbag, d_hbag (bag dtype; d_tk_scratch is bag-sized scratch) and the q / v / out-projection
+ * d_query, d_kbag (k_dtype; d_tk_scratch is scratch of the same size), d_hbag (bag dtype) and the q / v / out-projection
  * gradients; the key slices of d_in_proj_* are zeroed (the caller back-propagates d_kbag through its GEMM). */
 size_t mpo_nacagat_saved_floats(int n_slides, int n_q, int embed);
 size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_rows, int total_rows);
-int mpo_coattn_nacagat_forward(const void* kbag, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,
+int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,
                                int total_rows, int max_rows, const float* query, int n_q, int embed,
                                const float* in_proj_weight, const float* in_proj_bias,
                                const float* out_proj_weight, const float* out_proj_bias,
                                float drop_p, uint64_t seed, uint64_t offset,
                                void* tkbag, float* q_proj, float* out, float* attn_map, float* score_maps,
                                float* saved, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
-int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, const void* hbag, int bag_dtype,
+int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype, const void* hbag, int bag_dtype,
                                 const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
                                 const float* query, int n_q, int embed,
                                 const float* in_proj_weight, const float* in_proj_bias, const float* out_proj_weight,

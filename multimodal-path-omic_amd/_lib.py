@@ -38,9 +38,9 @@ _SIGNATURES = {
                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_nacagat_saved_floats": (c_size_t, [c_int, c_int, c_int]),
     "mpo_nacagat_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "mpo_coattn_nacagat_forward": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
+    "mpo_coattn_nacagat_forward": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                            c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "mpo_coattn_nacagat_backward": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
+    "mpo_coattn_nacagat_backward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
                                             c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P,
                                             _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
 }

@@ -198,7 +198,7 @@ size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_row
     return b + 256;
 }
 
-int mpo_coattn_nacagat_forward(const void* kbag, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,
+int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,
                                int total_rows, int max_rows, const float* query, int n_q, int embed,
                                const float* in_w, const float* in_b, const float* out_w, const float* out_b,
                                float drop_p, uint64_t seed, uint64_t offset,
@@ -207,7 +207,8 @@ int mpo_coattn_nacagat_forward(const void* kbag, const void* hbag, int bag_dtype
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
     MPO_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention dropout p must be in [0,1) (got %f)", (double)drop_p);
-    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32;
+    MPO_CHECK(k_dtype == MPO_F32 || k_dtype == MPO_BF16, "k dtype %d is neither MPO_F32 nor MPO_BF16", k_dtype);
+    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32, kf32 = k_dtype == MPO_F32;
     const int splits = mpo_coattn_splits(n_slides, max_rows);
     Arena ws(workspace, workspace_bytes);
     float* part = ws.floats((size_t)n_slides * splits * n_q * E);
@@ -225,9 +226,9 @@ int mpo_coattn_nacagat_forward(const void* kbag, const void* hbag, int bag_dtype
     // q = query W_q^T + b_q  (returned: the reference hands it to the CAG, models/blocks.py:110,206)
     if ((rc = mpo_linear_fwd(query, in_w, in_b, q_proj, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_launch_qprep(q_proj, qt, qs2, tq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
-    if ((rc = mpo_launch_bag_tanh_fwd(kbag, tkbag, (size_t)total_rows * E, f32, stream))) return rc;
-    if ((rc = mpo_launch_bag_rowdot(kbag, f32, cu_rows, n_slides, E, qs2, a_map, 1.0f, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_bag_rowdot(tkbag, f32, cu_rows, n_slides, E, tq, g_map, 1.0f, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_tanh_fwd(kbag, tkbag, (size_t)total_rows * E, kf32, stream))) return rc;
+    if ((rc = mpo_launch_bag_rowdot(kbag, kf32, cu_rows, n_slides, E, qs2, a_map, 1.0f, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_rowdot(tkbag, kf32, cu_rows, n_slides, E, tq, g_map, 1.0f, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_gated_softmax_fwd(a_map, g_map, cu_rows, attn_map, lse2, asum, n_slides, n_q, drop_p, seed, offset, stream))) return rc;
     if ((rc = mpo_launch_bag_colacc(hbag, f32, cu_rows, n_slides, E, attn_map, part, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part, ctx, n_slides, n_q, E, splits, stream))) return rc;
@@ -238,7 +239,7 @@ int mpo_coattn_nacagat_forward(const void* kbag, const void* hbag, int bag_dtype
     return 0;
 }
 
-int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, const void* hbag, int bag_dtype,
+int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype, const void* hbag, int bag_dtype,
                                 const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
                                 const float* query, int n_q, int embed, const float* in_w, const float* in_b,
                                 const float* out_w, float drop_p, uint64_t seed, uint64_t offset,
@@ -249,7 +250,8 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, const void*
                                 void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
-    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32;
+    MPO_CHECK(k_dtype == MPO_F32 || k_dtype == MPO_BF16, "k dtype %d is neither MPO_F32 nor MPO_BF16", k_dtype);
+    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32, kf32 = k_dtype == MPO_F32;
     const int splits = mpo_coattn_splits(n_slides, max_rows);
     Arena ws(workspace, workspace_bytes);
     float* dattn = ws.floats((size_t)R * E);
@@ -291,17 +293,17 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, const void*
     if ((rc = mpo_launch_gated_softmax_bwd(a_map, g_map, cu_rows, lse2, dasum, d_attn_map, ds1_map, dg_map, n_slides, n_q,
                                            drop_p, seed, offset, stream))) return rc;
     // query side: dq~ = ds1 K, dtq = dg TK
-    if ((rc = mpo_launch_bag_colacc(kbag, f32, cu_rows, n_slides, E, ds1_map, part, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_colacc(kbag, kf32, cu_rows, n_slides, E, ds1_map, part, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part, dqt, n_slides, n_q, E, splits, stream))) return rc;
-    if ((rc = mpo_launch_bag_colacc(tkbag, f32, cu_rows, n_slides, E, dg_map, part, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_colacc(tkbag, kf32, cu_rows, n_slides, E, dg_map, part, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part, dtq, n_slides, n_q, E, splits, stream))) return rc;
     if ((rc = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
     if ((rc = mpo_linear_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0, stream))) return rc;
     if ((rc = mpo_linear_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f, stream))) return rc;
     // bag side: dK = ds1^T q~ + (dg^T tq) * (1 - TK^2),  dH = A_drop^T dctx
-    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, ds1_map, qt, nullptr, nullptr, d_kbag, f32, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, dg_map, tq, nullptr, nullptr, d_tk_scratch, f32, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_bag_tanh_bwd(tkbag, d_tk_scratch, d_kbag, (size_t)total_rows * E, f32, stream))) return rc;
+    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, ds1_map, qt, nullptr, nullptr, d_kbag, kf32, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, dg_map, tq, nullptr, nullptr, d_tk_scratch, kf32, n_q, splits, stream))) return rc;
+    if ((rc = mpo_launch_bag_tanh_bwd(tkbag, d_tk_scratch, d_kbag, (size_t)total_rows * E, kf32, stream))) return rc;
     if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, attn_map, dctx, nullptr, nullptr, d_hbag, f32, n_q, splits, stream))) return rc;
     // the key slice of the packed in-projection belongs to the caller's K = H W_k^T + b_k
     MPO_HIP(hipMemsetAsync(d_in_w + (size_t)E * E, 0, (size_t)E * E * sizeof(float), stream));

@@ -239,7 +239,8 @@ def next_dropout_stream(n_elements: int):
 class CoAttnNaCAGaTFn(torch.autograd.Function):
     """NaCAGaT narrow-gated attention core over a ragged window (models/blocks.py:114-206).
     Returns (q_proj, attn_out, post-dropout map).  K = H W_k^T + b_k is a plain GEMM done here with
-    torch (hipBLASLt) in the bag's dtype, like the model's patch layer; everything else is HIP."""
+    torch (rocBLAS/hipBLASLt), like the model's patch layer; everything else is HIP.  K is always fp32,
+    also for a bf16-stored bag: the gate multiplies k's rounding error (hard part 4)."""
 
     @staticmethod
     def forward(ctx, query, bag_data, in_w, in_b, out_w, out_b, batch: BagBatch, drop_p: float):
@@ -249,8 +250,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         n_q = R // n_slides
         dev, T = query.device, batch.total_rows
         query = query.contiguous()
-        dt = bag_data.dtype
-        kbag = F.linear(bag_data, in_w[E:2 * E].to(dt), in_b[E:2 * E].to(dt))
+        kbag = F.linear(bag_data.float(), in_w[E:2 * E], in_b[E:2 * E])
         tkbag = torch.empty_like(kbag)
         q_proj = torch.empty(R, E, device=dev, dtype=torch.float32)
         out = torch.empty(R, E, device=dev, dtype=torch.float32)
@@ -260,7 +260,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         ws = _workspace(lib.mpo_nacagat_workspace_bytes(n_slides, n_q, E, batch.max_rows, T), dev)
         seed, offset = next_dropout_stream(n_q * T) if drop_p > 0 else (0, 0)
         L.check(lib.mpo_coattn_nacagat_forward(
-            L.ptr(kbag), L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, T, batch.max_rows,
+            L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, T, batch.max_rows,
             L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), L.ptr(out_b), float(drop_p), seed, offset,
             L.ptr(tkbag), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
             L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_forward")
@@ -289,16 +289,15 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         d_out_b = torch.empty(E, device=dev, dtype=torch.float32)
         ws = _workspace(lib.mpo_nacagat_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows, T), dev)
         L.check(lib.mpo_coattn_nacagat_backward(
-            L.ptr(kbag), L.ptr(tkbag), L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
+            L.ptr(kbag), L.ptr(tkbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
             L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
             L.ptr(d_query), L.ptr(d_k), L.ptr(d_tk), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
             L.ptr(d_out_b), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
         # back through the caller-side GEMM  K = H W_k^T + b_k
-        dt = bag_data.dtype
-        d_h = torch.addmm(d_h, d_k, in_w[E:2 * E].to(dt))
-        d_in_w[E:2 * E] = torch.mm(d_k.t(), bag_data).float()
-        d_in_b[E:2 * E] = d_k.float().sum(0)
+        d_h = torch.addmm(d_h.float(), d_k, in_w[E:2 * E]).to(bag_data.dtype)
+        d_in_w[E:2 * E] = torch.mm(d_k.t(), bag_data.float())
+        d_in_b[E:2 * E] = d_k.sum(0)
         return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None
 
 
