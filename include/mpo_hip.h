@@ -111,6 +111,64 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
                                 float* d_out_proj_weight, float* d_out_proj_bias,
                                 void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
+/* ==== the 6 x d token tail.  Parameter and gradient tensors are passed as arrays of device pointers in
+ * the order listed per entry (the reference's state_dict order); dropout streams are Philox counters
+ * (seed, offset): pass the same pair to forward and backward, reserve *_rng_span() counters per call. ==== */
+
+/* ---- K4: set-Transformer = nn.TransformerEncoder(post-norm layers, nhead, dim_feedforward, relu), no final
+ * norm.  Replaces models/mcat/mcat.py:51-53,60-62 (call :101-102); torch/nn/modules/transformer.py:661.
+ * x, y [n_slides*T, d]; per layer 12 pointers: self_attn.in_proj_weight, in_proj_bias, out_proj.weight,
+ * out_proj.bias, linear1.weight, .bias, linear2.weight, .bias, norm1.weight, .bias, norm2.weight, .bias. */
+size_t mpo_encoder_saved_floats(int n_slides, int T, int d, int ff, int heads, int layers);
+size_t mpo_encoder_workspace_bytes(int n_slides, int T, int d, int ff);
+uint64_t mpo_encoder_rng_span(int n_slides, int T, int d, int ff, int layers);
+int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
+                        const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                        float* y, float* saved, mpo_stream_t stream);
+int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
+                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                         const float* saved, const float* dy, float* dx, float* const* grads,
+                         void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
+/* ---- K5: gated attention-MIL pooling = AttentionNetGated (models/blocks.py:13-48) + softmax pooling + rho
+ * (models/mcat/mcat.py:105-109).  x [n_slides*L, d] -> scores [n_slides*L] (raw A), h [n_slides, d].
+ * 8 pointers: attention_a.0.weight, .bias, attention_b.0.weight, .bias, attention_c.weight, .bias, rho.0.weight, .bias */
+size_t mpo_gated_pool_saved_floats(int n_slides, int L, int d);
+size_t mpo_gated_pool_workspace_bytes(int n_slides, int L, int d);
+uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d);
+int mpo_gated_pool_forward(const float* x, int n_slides, int L, int d, const float* const* params,
+                           float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset,
+                           float* scores, float* h, float* saved, mpo_stream_t stream);
+int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const float* const* params,
+                            float head_drop_p, float rho_drop_p, const float* saved, const float* h,
+                            const float* dh, const float* d_scores_ext /* nullable */, float* dx, float* const* grads,
+                            void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
+/* ---- K6: ConcatFusion (models/fusion.py:7-19) + classifier + survival head (models/mcat/mcat.py:119-138).
+ * hcat [n_slides, din] = [h_path | h_omic] -> hazards, survs, Y [n_slides, n_classes].
+ * 6 pointers: fusion_layer.0.weight, .bias, fusion_layer.2.weight, .bias, classifier.weight, .bias */
+size_t mpo_fusion_head_saved_floats(int n_slides, int hidden, int dout, int n_classes);
+size_t mpo_fusion_head_workspace_bytes(int n_slides, int hidden, int dout, int n_classes);
+int mpo_fusion_head_forward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
+                            const float* const* params, float* hazards, float* survs, float* y, float* saved,
+                            mpo_stream_t stream);
+int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
+                             const float* const* params, const float* saved, const float* hazards,
+                             const float* survs, const float* y, const float* d_hazards, const float* d_survs,
+                             const float* d_y, float* d_hcat, float* const* grads,
+                             void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
+/* ---- K3: ContextualAttentionGate.forward (models/blocks.py:232-253) on rows of (Q, Q_hat).
+ * 12 pointers: fc1.0.weight,.bias, fc2.0.weight,.bias, fc3.0.weight,.bias, G.1.weight,.bias, E.1.weight,.bias,
+ * fc_c.0.weight,.bias */
+size_t mpo_cag_saved_floats(int rows, int hidden);
+size_t mpo_cag_workspace_bytes(int rows, int hidden);
+int mpo_cag_forward(const float* q, const float* q_hat, int rows, int dim, int hidden, const float* const* params,
+                    float* c_out, float* saved, mpo_stream_t stream);
+int mpo_cag_backward(const float* q, const float* q_hat, int rows, int dim, int hidden, const float* const* params,
+                     const float* saved, const float* c_out, const float* d_c, float* d_q, float* d_q_hat,
+                     float* const* grads, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
 /* ---- the two bag-pass kernels of K1 on their own (bench.py times them with HIP events for the
  * roofline line; tests use them for kernel-level checks).  qk2 = log2(e) * (q/sqrt(E)) W_k, [n_slides*n_q, embed].
  * part_ml [n_slides*splits*32], part_ctx [n_slides*splits*n_q*embed] with splits = mpo_coattn_splits(). */

@@ -43,6 +43,24 @@ _SIGNATURES = {
     "mpo_coattn_nacagat_backward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
                                             c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P,
                                             _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_encoder_saved_floats": (c_size_t, [c_int] * 6),
+    "mpo_encoder_workspace_bytes": (c_size_t, [c_int] * 4),
+    "mpo_encoder_rng_span": (c_uint64, [c_int] * 5),
+    "mpo_encoder_forward": (c_int, [_P] + [c_int] * 6 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P]),
+    "mpo_encoder_backward": (c_int, [_P] + [c_int] * 6 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_gated_pool_saved_floats": (c_size_t, [c_int] * 3),
+    "mpo_gated_pool_workspace_bytes": (c_size_t, [c_int] * 3),
+    "mpo_gated_pool_rng_span": (c_uint64, [c_int] * 3),
+    "mpo_gated_pool_forward": (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, c_uint64, c_uint64, _P, _P, _P, _P]),
+    "mpo_gated_pool_backward": (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_fusion_head_saved_floats": (c_size_t, [c_int] * 4),
+    "mpo_fusion_head_workspace_bytes": (c_size_t, [c_int] * 4),
+    "mpo_fusion_head_forward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P, _P, _P]),
+    "mpo_fusion_head_backward": (c_int, [_P] + [c_int] * 5 + [_P] * 10 + [c_size_t, _P]),
+    "mpo_cag_saved_floats": (c_size_t, [c_int] * 2),
+    "mpo_cag_workspace_bytes": (c_size_t, [c_int] * 2),
+    "mpo_cag_forward": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "mpo_cag_backward": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
 }
 
 
@@ -82,6 +100,14 @@ def ptr(t):
     if not t.is_contiguous():
         raise RuntimeError("libmpo_hip needs contiguous tensors")
     return t.data_ptr()
+
+
+def ptr_array(tensors):
+    """ctypes array of device pointers (kept alive by the caller for the duration of the call)."""
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t)
+    return arr
 
 
 def stream_of(t):

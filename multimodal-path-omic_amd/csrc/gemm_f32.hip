@@ -34,10 +34,53 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+struct GateFn {
+    const float* g;
+    int mode;
+    float p, inv_keep;
+    uint64_t seed, off;
+    __device__ __forceinline__ float operator()(float gv, size_t idx) const {
+        switch (mode) {
+            case MPO_GATE_RELU: return gv > 0.f ? inv_keep : 0.f;
+            case MPO_GATE_ELU: return gv > 0.f ? 1.0f : gv + 1.0f;
+            case MPO_GATE_TANH: {
+                if (gv == 0.f) return p > 0.f ? 0.f : 1.0f;
+                const float t = gv * (1.0f - p);
+                return (1.0f - t * t) * inv_keep;
+            }
+            case MPO_GATE_SIGMOID: {
+                if (gv == 0.f) return 0.f;
+                const float sg = gv * (1.0f - p);
+                return sg * (1.0f - sg) * inv_keep;
+            }
+            case MPO_GATE_RNG: return dropout_keep(seed, off, idx, p, inv_keep);
+            case MPO_GATE_MUL: return gv;
+            default: return 1.0f;
+        }
+    }
+};
+
 // One operand tile (32 rows x KC k) in flight in registers: 8 float4 per thread.
 template <bool KCONTIG>
 struct OperandStage {
     f32x4 v[8];
+    // multiply the staged values by the gate of the same (mn, k) elements (same layout/ld as the operand)
+    __device__ __forceinline__ void apply_gate(const GateFn& gf, int ld, int mn0, int mn_lim, int k0, int k_lim, int tid) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = i * 256 + tid;
+            int mn, k;
+            if (KCONTIG) { mn = f >> 6; k = (f & 63) << 2; } else { k = f >> 3; mn = (f & 7) << 2; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gmn = mn0 + mn + (KCONTIG ? 0 : j), gk = k0 + k + (KCONTIG ? j : 0);
+                if (gmn < mn_lim && gk < k_lim) {
+                    const size_t idx = KCONTIG ? (size_t)gmn * ld + gk : (size_t)gk * ld + gmn;
+                    v[i][j] *= gf(gf.g ? gf.g[idx] : 0.f, idx);
+                }
+            }
+        }
+    }
     // element (mn, k) lives at p[mn*ld + k] (KCONTIG) or p[k*ld + mn]
     __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int mn0, int mn_lim, int k0, int k_lim,
                                          bool vec_ok, int tid) {
@@ -97,21 +140,33 @@ void gemm_f32_kernel(GemmArgs g) {
     const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
     const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
 
+    GateFn gf;
+    gf.g = g.gate; gf.mode = g.gate_mode; gf.p = g.gate_p; gf.seed = g.gate_seed; gf.off = g.gate_off;
+    gf.inv_keep = g.gate_p > 0.f ? 1.0f / (1.0f - g.gate_p) : 1.0f;
+    const bool gated = g.gate_mode != MPO_GATE_NONE;
+
     OperandStage<A_KC> sa;
     OperandStage<B_KC> sb;
     sa.load(g.A, g.lda, m0, g.M, 0, g.K, a_vec, tid);
+    if (gated) sa.apply_gate(gf, g.lda, m0, g.M, 0, g.K, tid);
     sb.load(g.B, g.ldb, n0, g.N, 0, g.K, b_vec, tid);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                                           // bias gradient: row sums of the (gated) A tile
 
     for (int k0 = 0; k0 < g.K; k0 += KC) {
         sa.store(As, tid);
         sb.store(Bs, tid);
         if (k0 + KC < g.K) {                                    // next chunk flies under this chunk's MFMAs
             sa.load(g.A, g.lda, m0, g.M, k0 + KC, g.K, a_vec, tid);
+            if (gated) sa.apply_gate(gf, g.lda, m0, g.M, k0 + KC, g.K, tid);
             sb.load(g.B, g.ldb, n0, g.N, k0 + KC, g.K, b_vec, tid);
         }
         __syncthreads();
         const int kblocks = (min(KC, g.K - k0) + 15) >> 4;
+        if (g.bias_grad != nullptr && blockIdx.x == 0 && tid < BM) {
+            const float* row = As + tid * LDK;
+            for (int k = 0; k < 16 * kblocks; ++k) bsum += row[k];
+        }
         const float* ap = As + (16 * wm + i16) * LDK + 4 * kq;
         const float* bp = Bs + (16 * wn + i16) * LDK + 4 * kq;
         for (int kk = 0; kk < kblocks; ++kk) {
@@ -135,12 +190,14 @@ void gemm_f32_kernel(GemmArgs g) {
             float v = (acc0[r] + acc1[r] + bias) * g.alpha;
             v = apply_act(v, g.act);
             const size_t o = (size_t)m * g.ldc + n;
+            if (g.drop_p > 0.f) v *= dropout_keep(g.drop_seed, g.drop_off, o, g.drop_p, 1.0f / (1.0f - g.drop_p));
             if (g.mask) v *= g.mask[o];
             if (g.residual) v += g.residual[o];
             if (g.accumulate) v += g.C[o];
             g.C[o] = v;
         }
     }
+    if (g.bias_grad != nullptr && blockIdx.x == 0 && tid < BM && m0 + tid < g.M) g.bias_grad[m0 + tid] = bsum;
 }
 
 // colsum[n] (+)= sum_m X[m][n]   (bias gradients): 64 columns per workgroup, 4 waves split the rows

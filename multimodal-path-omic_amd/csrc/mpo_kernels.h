@@ -4,7 +4,19 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include <stdint.h>
 enum { MPO_ACT_NONE = 0, MPO_ACT_RELU = 1, MPO_ACT_ELU = 2, MPO_ACT_TANH = 3, MPO_ACT_SIGMOID = 4 };
+// Gate applied to the A operand while it is staged: A(m,k) *= gate_fn(G(m,k)), G laid out like A.
+// It folds the derivative of the activation (and of a following dropout) of the layer that PRODUCED
+// the saved tensor G into the backward GEMMs dx = (dy*gate) W and dW = (dy*gate)^T x:
+//   RELU    G = drop(relu(pre)):    G > 0 ? 1/(1-p) : 0
+//   ELU     G = elu(pre):           G > 0 ? 1 : G + 1
+//   TANH    G = drop(tanh(pre)):    t = G(1-p);  G != 0 ? (1 - t^2)/(1-p) : (p > 0 ? 0 : 1)
+//   SIGMOID G = drop(sigmoid(pre)): s = G(1-p);  G != 0 ? s(1-s)/(1-p) : 0
+//   RNG     no tensor: the keep-scale of the dropout stream (gate_seed, gate_off) at the element's index
+//   MUL     plain element-wise factor G
+enum { MPO_GATE_NONE = 0, MPO_GATE_RELU = 1, MPO_GATE_ELU = 2, MPO_GATE_TANH = 3, MPO_GATE_SIGMOID = 4,
+       MPO_GATE_RNG = 5, MPO_GATE_MUL = 6 };
 
 struct GemmArgs {
     const float* A = nullptr;
@@ -18,37 +30,60 @@ struct GemmArgs {
     float alpha = 1.0f;
     int act = MPO_ACT_NONE;
     int accumulate = 0;                // C += result
+    // epilogue dropout (after the activation): C *= keep-scale of stream (drop_seed, drop_off) at index m*ldc+n
+    float drop_p = 0.f;
+    uint64_t drop_seed = 0, drop_off = 0;
+    // A-operand gate (see MPO_GATE_*)
+    const float* gate = nullptr;
+    int gate_mode = MPO_GATE_NONE;
+    float gate_p = 0.f;
+    uint64_t gate_seed = 0, gate_off = 0;
+    // dW GEMMs: bias_grad[m] = sum_k A(m,k) (after the gate) -- the bias gradient, for free
+    float* bias_grad = nullptr;
+};
+
+struct DropSpec {                      // one dropout stream: p = 0 means "no dropout"
+    float p = 0.f;
+    uint64_t seed = 0, off = 0;
+};
+struct GateSpec {
+    const float* g = nullptr;
+    int mode = MPO_GATE_NONE;
+    float p = 0.f;
+    uint64_t seed = 0, off = 0;
 };
 
 int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream);
 int mpo_launch_colsum(const float* x, float* out, int M, int N, int ld, int accumulate, hipStream_t stream);
 
-// y[R][O] = act(alpha * (x[R][I] W[O][I]^T + b))
+// y[R][O] = drop(act(alpha * (x[R][I] W[O][I]^T + b))) [+ residual]
 inline int mpo_linear_fwd(const float* x, const float* w, const float* b, float* y, int R, int I, int O,
-                          float alpha, int act, hipStream_t s) {
+                          float alpha, int act, hipStream_t s, const float* residual = nullptr,
+                          DropSpec drop = DropSpec()) {
     GemmArgs g;
-    g.A = x; g.B = w; g.C = y; g.bias = b;
+    g.A = x; g.B = w; g.C = y; g.bias = b; g.residual = residual;
     g.M = R; g.N = O; g.K = I; g.lda = I; g.ldb = I; g.ldc = O; g.alpha = alpha; g.act = act;
+    g.drop_p = drop.p; g.drop_seed = drop.seed; g.drop_off = drop.off;
     return mpo_launch_gemm(g, 1, 1, s);
 }
-// dx[R][I] (+)= alpha * dy[R][O] W[O][I]
+// dx[R][I] (+)= alpha * (dy*gate)[R][O] W[O][I]
 inline int mpo_linear_bwd_input(const float* dy, const float* w, float* dx, int R, int I, int O, float alpha,
-                                int accumulate, hipStream_t s) {
+                                int accumulate, hipStream_t s, GateSpec gate = GateSpec()) {
     GemmArgs g;
     g.A = dy; g.B = w; g.C = dx;
     g.M = R; g.N = I; g.K = O; g.lda = O; g.ldb = I; g.ldc = I; g.alpha = alpha; g.accumulate = accumulate;
+    g.gate = gate.g; g.gate_mode = gate.mode; g.gate_p = gate.p; g.gate_seed = gate.seed; g.gate_off = gate.off;
     return mpo_launch_gemm(g, 1, 0, s);
 }
-// dW[O][I] = alpha * dy[R][O]^T x[R][I]   (ldw = row stride of dW),   db[O] = alpha-less column sums of dy
+// dW[O][I] = alpha * (dy*gate)[R][O]^T x[R][I],   db[O] = column sums of dy*gate (nullable)
 inline int mpo_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int R, int I, int O,
-                                 float alpha, hipStream_t s) {
+                                 float alpha, hipStream_t s, GateSpec gate = GateSpec()) {
     GemmArgs g;
     g.A = dy; g.B = x; g.C = dw;
     g.M = O; g.N = I; g.K = R; g.lda = O; g.ldb = I; g.ldc = I; g.alpha = alpha;
-    int rc = mpo_launch_gemm(g, 0, 0, s);
-    if (rc) return rc;
-    if (db) return mpo_launch_colsum(dy, db, R, O, O, 0, s);
-    return 0;
+    g.gate = gate.g; g.gate_mode = gate.mode; g.gate_p = gate.p; g.gate_seed = gate.seed; g.gate_off = gate.off;
+    g.bias_grad = db;
+    return mpo_launch_gemm(g, 0, 0, s);
 }
 
 // ---- K1/K2 long-bag cross-attention (coattn_fwd.hip / coattn_bwd.hip)
@@ -90,3 +125,29 @@ int mpo_launch_qprep(const float* q, float* qt, float* qs2, float* tq, int n, fl
 int mpo_launch_qprep_bwd(const float* dqt, const float* dtq, const float* tq, const float* d_ext, float* dq, int n,
                          float c_nat, hipStream_t stream);
 int mpo_launch_row_scaled_bias(float* y, const float* s, const float* bias, int rows, int cols, hipStream_t stream);
+
+// ---- tail kernels (tail.hip)
+int mpo_launch_ln_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int rows, int d, float eps,
+                      hipStream_t s);
+int mpo_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* w, float* dx, float* dw, float* db,
+                      int rows, int d, int accumulate, hipStream_t s);
+int mpo_launch_ln_bwd_params_only(const float* dy, const float* x, const float* stats, float* dw, float* db, int rows, int d,
+                                  hipStream_t s);
+int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, int T, int d, int H, float drop_p,
+                             unsigned long long seed, unsigned long long offset, hipStream_t s);
+int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float* d_o, float* dqkv, int B, int T, int d, int H,
+                             hipStream_t s);
+int mpo_launch_pool_fwd(const float* scores, const float* x, float* w, float* h, int B, int L, int d, hipStream_t s);
+int mpo_launch_pool_bwd(const float* dh, const float* x, const float* w, const float* d_ext, float* d_scores, float* dx,
+                        int B, int L, int d, hipStream_t s);
+int mpo_launch_head_fwd(const float* logits, float* hazards, float* survs, float* y, int B, int C, hipStream_t s);
+int mpo_launch_head_bwd(const float* hazards, const float* survs, const float* y, const float* dhz, const float* dsv,
+                        const float* dy, float* dlogits, int B, int C, hipStream_t s);
+int mpo_launch_ew_mul(const float* a, const float* b, float* out, int n, hipStream_t s);
+int mpo_launch_ew_add(const float* a, const float* b, float* out, int n, hipStream_t s);
+int mpo_launch_cag_mid_fwd(const float* u1, const float* u2, const float* u3, const float* gw, const float* gb, const float* ew,
+                           const float* eb, float* t1, float* t3, float* gout, float* eout, float* m, float* stats_g, float* stats_e,
+                           int rows, int d, float eps, hipStream_t s);
+int mpo_launch_cag_mid_bwd(const float* dm, const float* t1, const float* t3, const float* gout, const float* eout,
+                           const float* gw, const float* ew, const float* stats_g, const float* stats_e, float* dG, float* dE,
+                           float* ds12, float* ds3, int rows, int d, hipStream_t s);

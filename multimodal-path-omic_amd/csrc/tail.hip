@@ -1,0 +1,449 @@
+// Kernels of the 6 x d token tail that are not GEMMs (K3 CAG, K4 set-Transformer,
+// K5 gated attention-MIL pooling, K6 fusion head).  Every linear of the tail runs on gemm_f32.hip with
+// fused bias / activation / dropout / residual epilogues and fused activation-derivative gates; what is
+// left is LayerNorm, the 8-head self-attention over T = N tokens of one slide, the softmax pooling and
+// the survival head.  All of it is launch-latency-bound small-row work: one wave per row or one
+// workgroup per slide, fp32 throughout.
+#include "mpo_common.h"
+#include "mpo_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.0f : y + 1.0f; }
+
+// ------------------------------------------------------------------ LayerNorm (one wave per row)
+__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                              float* __restrict__ y, float* __restrict__ stats, int rows, int d, float eps) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (size_t)r * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / d;
+    float v = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; v += t * t; }
+    const float rstd = rsqrtf(wave_sum(v) / d + eps);
+    for (int c = lane; c < d; c += 64) y[(size_t)r * d + c] = (xr[c] - mean) * rstd * w[c] + b[c];
+    if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w    [dx may alias dy]
+__global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
+                              const float* __restrict__ w, float* __restrict__ dx, int rows, int d, int accumulate) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    float c1 = 0.f, c2 = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float g = dy[(size_t)r * d + c] * w[c];
+        const float xh = (x[(size_t)r * d + c] - mean) * rstd;
+        c1 += g;
+        c2 += g * xh;
+    }
+    c1 = wave_sum(c1) / d;
+    c2 = wave_sum(c2) / d;
+    for (int c = lane; c < d; c += 64) {
+        const float g = dy[(size_t)r * d + c] * w[c];
+        const float xh = (x[(size_t)r * d + c] - mean) * rstd;
+        const float v = rstd * (g - c1 - xh * c2);
+        dx[(size_t)r * d + c] = accumulate ? dx[(size_t)r * d + c] + v : v;
+    }
+}
+
+// dw[c] = sum_r dy * xhat,  db[c] = sum_r dy      (64 columns per workgroup, 4 waves split the rows)
+__global__ void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
+                                     float* __restrict__ dw, float* __restrict__ db, int rows, int d) {
+    __shared__ float red[2][4][64];
+    const int c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float a = 0.f, bsum = 0.f;
+    if (col < d)
+        for (int r = wv; r < rows; r += 4) {
+            const float g = dy[(size_t)r * d + col];
+            a += g * (x[(size_t)r * d + col] - stats[2 * r]) * stats[2 * r + 1];
+            bsum += g;
+        }
+    red[0][wv][c] = a;
+    red[1][wv][c] = bsum;
+    __syncthreads();
+    if (wv == 0 && col < d) {
+        dw[col] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        db[col] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    }
+}
+
+// ------------------------------------------------------------------ self-attention over the T tokens of one slide
+// qkv [B*T][3d] (q | k | v), H heads of hd = d / H.  One workgroup per slide, everything through LDS.
+constexpr int kMaxT = 16;
+
+__global__ __launch_bounds__(256)
+void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ p_save /* [B][H][T][T] x2: p, p_post */,
+                          int T, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset) {
+    extern __shared__ float sm[];
+    float* sq = sm;                       // [T][3d]
+    float* sp = sm + T * 3 * d;           // [H][T][T]
+    const int b = blockIdx.x, hd = d / H, tid = threadIdx.x;
+    const float scale = rsqrtf((float)hd);
+    for (int i = tid; i < T * 3 * d; i += 256) sq[i] = qkv[(size_t)b * T * 3 * d + i];
+    __syncthreads();
+    for (int it = tid; it < H * T * T; it += 256) {
+        const int h = it / (T * T), i = (it / T) % T, j = it % T;
+        const float* qi = sq + i * 3 * d + h * hd;
+        const float* kj = sq + j * 3 * d + d + h * hd;
+        float s = 0.f;
+        for (int c = 0; c < hd; ++c) s += qi[c] * kj[c];
+        sp[it] = s * scale;
+    }
+    __syncthreads();
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    float* pb = p_save + (size_t)b * 2 * H * T * T;
+    for (int it = tid; it < H * T; it += 256) {
+        float* row = sp + it * T;
+        float mx = row[0];
+        for (int j = 1; j < T; ++j) mx = fmaxf(mx, row[j]);
+        float l = 0.f;
+        for (int j = 0; j < T; ++j) { row[j] = __expf(row[j] - mx); l += row[j]; }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < T; ++j) {
+            const float p = row[j] * inv;
+            float pp = p;
+            if (drop_p > 0.f) pp *= dropout_keep(seed, offset, ((size_t)b * H * T + it) * T + j, drop_p, inv_keep);
+            pb[it * T + j] = p;
+            pb[H * T * T + it * T + j] = pp;
+            row[j] = pp;
+        }
+    }
+    __syncthreads();
+    for (int it = tid; it < T * d; it += 256) {
+        const int i = it / d, c = it % d, h = c / hd;
+        const float* pr = sp + (h * T + i) * T;
+        float a = 0.f;
+        for (int j = 0; j < T; ++j) a += pr[j] * sq[j * 3 * d + 2 * d + c];
+        o[((size_t)b * T + i) * d + c] = a;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void mha_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ p_save, const float* __restrict__ d_o,
+                          float* __restrict__ dqkv, int T, int d, int H) {
+    extern __shared__ float sm[];
+    float* sq = sm;                       // [T][3d]
+    float* sdo = sq + T * 3 * d;          // [T][d]
+    float* sds = sdo + T * d;             // [H][T][T]  dS
+    const int b = blockIdx.x, hd = d / H, tid = threadIdx.x;
+    const float scale = rsqrtf((float)hd);
+    for (int i = tid; i < T * 3 * d; i += 256) sq[i] = qkv[(size_t)b * T * 3 * d + i];
+    for (int i = tid; i < T * d; i += 256) sdo[i] = d_o[(size_t)b * T * d + i];
+    __syncthreads();
+    const float* pb = p_save + (size_t)b * 2 * H * T * T;
+    const float* ppb = pb + H * T * T;
+    for (int it = tid; it < H * T; it += 256) {
+        const int h = it / T, i = it % T;
+        float dp[kMaxT];
+        float delta = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const float* vj = sq + j * 3 * d + 2 * d + h * hd;
+            const float* doi = sdo + i * d + h * hd;
+            float a = 0.f;
+            for (int c = 0; c < hd; ++c) a += doi[c] * vj[c];
+            const float p = pb[it * T + j];
+            const float ks = p > 0.f ? ppb[it * T + j] / p : 0.f;
+            dp[j] = a * ks;
+            delta += p * dp[j];
+        }
+        for (int j = 0; j < T; ++j) sds[it * T + j] = pb[it * T + j] * (dp[j] - delta) * scale;
+    }
+    __syncthreads();
+    float* out = dqkv + (size_t)b * T * 3 * d;
+    for (int it = tid; it < T * d; it += 256) {
+        const int t = it / d, c = it % d, h = c / hd;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int u = 0; u < T; ++u) {
+            dq += sds[(h * T + t) * T + u] * sq[u * 3 * d + d + c];          // dS[t][u] k[u]
+            dk += sds[(h * T + u) * T + t] * sq[u * 3 * d + c];              // dS[u][t] q[u]
+            dv += ppb[(h * T + u) * T + t] * sdo[u * d + c];                 // Ppost[u][t] do[u]
+        }
+        out[t * 3 * d + c] = dq;
+        out[t * 3 * d + d + c] = dk;
+        out[t * 3 * d + 2 * d + c] = dv;
+    }
+}
+
+// ------------------------------------------------------------------ softmax pooling over the L rows of a slide
+// scores [B*L] raw, x [B*L][d] -> w [B*L] = softmax_l(scores), h [B][d] = sum_l w_l x_l.  One workgroup per slide.
+__device__ __forceinline__ float blk_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float blk_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256)
+void pool_fwd_kernel(const float* __restrict__ scores, const float* __restrict__ x, float* __restrict__ w,
+                     float* __restrict__ h, int L, int d) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* sc = scores + (size_t)b * L;
+    float mx = -INFINITY;
+    for (int l = tid; l < L; l += 256) mx = fmaxf(mx, sc[l]);
+    mx = blk_max(mx, red);
+    float s = 0.f;
+    for (int l = tid; l < L; l += 256) s += __expf(sc[l] - mx);
+    s = blk_sum(s, red);
+    const float inv = 1.0f / s;
+    for (int l = tid; l < L; l += 256) w[(size_t)b * L + l] = __expf(sc[l] - mx) * inv;
+    __syncthreads();
+    for (int c = tid; c < d; c += 256) {
+        float a = 0.f;
+        for (int l = 0; l < L; ++l) a += w[(size_t)b * L + l] * x[((size_t)b * L + l) * d + c];
+        h[(size_t)b * d + c] = a;
+    }
+}
+
+// dh [B][d], optional d_scores_ext [B*L] -> d_scores [B*L], dx [B*L][d] = w_l dh
+__global__ __launch_bounds__(256)
+void pool_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ w,
+                     const float* __restrict__ d_ext, float* __restrict__ d_scores, float* __restrict__ dx, int L, int d) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* dhb = dh + (size_t)b * d;
+    // dw_l = dh . x_l  (one wave per row, strided), stashed in d_scores
+    for (int l = wv; l < L; l += 4) {
+        float a = 0.f;
+        for (int c = lane; c < d; c += 64) a += dhb[c] * x[((size_t)b * L + l) * d + c];
+        a = wave_sum(a);
+        if (lane == 0) d_scores[(size_t)b * L + l] = a;
+    }
+    __syncthreads();
+    float dl = 0.f;
+    for (int l = tid; l < L; l += 256) dl += w[(size_t)b * L + l] * d_scores[(size_t)b * L + l];
+    dl = blk_sum(dl, red);
+    for (int l = tid; l < L; l += 256) {
+        const size_t i = (size_t)b * L + l;
+        d_scores[i] = w[i] * (d_scores[i] - dl) + (d_ext ? d_ext[i] : 0.f);
+    }
+    for (int it = tid; it < L * d; it += 256) {
+        const int l = it / d, c = it % d;
+        dx[((size_t)b * L + l) * d + c] = w[(size_t)b * L + l] * dhb[c];
+    }
+}
+
+// ------------------------------------------------------------------ survival head (models/mcat/mcat.py:126-138)
+constexpr int kMaxC = 16;
+__global__ void head_fwd_kernel(const float* __restrict__ logits, float* __restrict__ hazards, float* __restrict__ survs,
+                                float* __restrict__ y, int B, int C) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* lg = logits + (size_t)b * C;
+    float mx = lg[0];
+    for (int j = 1; j < C; ++j) mx = fmaxf(mx, lg[j]);
+    float s = 0.f, run = 1.0f;
+    for (int j = 0; j < C; ++j) s += __expf(lg[j] - mx);
+    for (int j = 0; j < C; ++j) {
+        const float hz = 1.0f / (1.0f + __expf(-lg[j]));
+        run *= 1.0f - hz;
+        hazards[(size_t)b * C + j] = hz;
+        survs[(size_t)b * C + j] = run;
+        y[(size_t)b * C + j] = __expf(lg[j] - mx) / s;
+    }
+}
+__global__ void head_bwd_kernel(const float* __restrict__ hazards, const float* __restrict__ survs, const float* __restrict__ y,
+                                const float* __restrict__ dhz, const float* __restrict__ dsv, const float* __restrict__ dy,
+                                float* __restrict__ dlogits, int B, int C) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t o = (size_t)b * C;
+    float ydot = 0.f;
+    if (dy) for (int j = 0; j < C; ++j) ydot += y[o + j] * dy[o + j];
+    float tail = 0.f;                                   // sum_{j >= i} dS_j S_j, built from the back
+    float dl[kMaxC];
+    for (int i = C - 1; i >= 0; --i) {
+        if (dsv) tail += dsv[o + i] * survs[o + i];
+        const float hz = hazards[o + i];
+        float dh = dhz ? dhz[o + i] : 0.f;
+        dh -= tail / fmaxf(1.0f - hz, 1e-30f);
+        dl[i] = dh * hz * (1.0f - hz) + (dy ? y[o + i] * (dy[o + i] - ydot) : 0.f);
+    }
+    for (int i = 0; i < C; ++i) dlogits[o + i] = dl[i];
+}
+
+// ------------------------------------------------------------------ element-wise helpers
+__global__ void ew_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+__global__ void ew_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+// CAG middle (models/blocks.py:248-250), one wave per row:
+//   t1 = ELU(u1 + u2), G = LN_G(t1);  t3 = ELU(u3), E = LN_E(t3);  m = G * E
+__global__ void cag_mid_fwd_kernel(const float* __restrict__ u1, const float* __restrict__ u2, const float* __restrict__ u3,
+                                   const float* __restrict__ gw, const float* __restrict__ gb,
+                                   const float* __restrict__ ew, const float* __restrict__ eb,
+                                   float* __restrict__ t1, float* __restrict__ t3, float* __restrict__ gout,
+                                   float* __restrict__ eout, float* __restrict__ m, float* __restrict__ stats_g /* [R][2] */,
+                                   float* __restrict__ stats_e /* [R][2] */, int rows, int d, float eps) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const size_t o = (size_t)r * d;
+    float s1 = 0.f, s3 = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float a = elu_f(u1[o + c] + u2[o + c]), b = elu_f(u3[o + c]);
+        t1[o + c] = a;
+        t3[o + c] = b;
+        s1 += a;
+        s3 += b;
+    }
+    const float m1 = wave_sum(s1) / d, m3 = wave_sum(s3) / d;
+    float v1 = 0.f, v3 = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float a = t1[o + c] - m1, b = t3[o + c] - m3;
+        v1 += a * a;
+        v3 += b * b;
+    }
+    const float r1 = rsqrtf(wave_sum(v1) / d + eps), r3 = rsqrtf(wave_sum(v3) / d + eps);
+    for (int c = lane; c < d; c += 64) {
+        const float g = (t1[o + c] - m1) * r1 * gw[c] + gb[c];
+        const float e = (t3[o + c] - m3) * r3 * ew[c] + eb[c];
+        gout[o + c] = g;
+        eout[o + c] = e;
+        m[o + c] = g * e;
+    }
+    if (lane == 0) { stats_g[2 * r] = m1; stats_g[2 * r + 1] = r1; stats_e[2 * r] = m3; stats_e[2 * r + 1] = r3; }
+}
+
+// dm -> dG = dm*E, dE = dm*G (written for the LN parameter gradients) and, through both LayerNorms and the
+// outer ELUs, ds12 = d(u1 + u2) and ds3 = d(ELU(u3)).
+__global__ void cag_mid_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ t1, const float* __restrict__ t3,
+                                   const float* __restrict__ gout, const float* __restrict__ eout,
+                                   const float* __restrict__ gw, const float* __restrict__ ew, const float* __restrict__ stats_g,
+                                   const float* __restrict__ stats_e, float* __restrict__ dG, float* __restrict__ dE, float* __restrict__ ds12, float* __restrict__ ds3,
+                                   int rows, int d) {
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const size_t o = (size_t)r * d;
+    const float m1 = stats_g[2 * r], r1 = stats_g[2 * r + 1], m3 = stats_e[2 * r], r3 = stats_e[2 * r + 1];
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float dg = dm[o + c] * eout[o + c], de = dm[o + c] * gout[o + c];
+        dG[o + c] = dg;
+        dE[o + c] = de;
+        const float g1 = dg * gw[c], x1 = (t1[o + c] - m1) * r1;
+        const float g3 = de * ew[c], x3 = (t3[o + c] - m3) * r3;
+        a1 += g1; a2 += g1 * x1; b1 += g3; b2 += g3 * x3;
+    }
+    a1 = wave_sum(a1) / d; a2 = wave_sum(a2) / d; b1 = wave_sum(b1) / d; b2 = wave_sum(b2) / d;
+    for (int c = lane; c < d; c += 64) {
+        const float g1 = dG[o + c] * gw[c], x1 = (t1[o + c] - m1) * r1;
+        const float g3 = dE[o + c] * ew[c], x3 = (t3[o + c] - m3) * r3;
+        ds12[o + c] = r1 * (g1 - a1 - x1 * a2) * elu_grad_from_out(t1[o + c]);
+        ds3[o + c] = r3 * (g3 - b1 - x3 * b2) * elu_grad_from_out(t3[o + c]);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- launchers
+int mpo_launch_ln_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int rows, int d, float eps,
+                      hipStream_t s) {
+    if (rows <= 0) return 0;
+    ln_fwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(x, w, b, y, stats, rows, d, eps);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* w, float* dx, float* dw, float* db,
+                      int rows, int d, int accumulate, hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (dw) {
+        ln_bwd_params_kernel<<<(d + 63) / 64, 256, 0, s>>>(dy, x, stats, dw, db, rows, d);
+        MPO_LAUNCH_CHECK();
+    }
+    ln_bwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(dy, x, stats, w, dx, rows, d, accumulate);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_ln_bwd_params_only(const float* dy, const float* x, const float* stats, float* dw, float* db, int rows, int d,
+                                  hipStream_t s) {
+    ln_bwd_params_kernel<<<(d + 63) / 64, 256, 0, s>>>(dy, x, stats, dw, db, rows, d);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, int T, int d, int H, float drop_p,
+                             unsigned long long seed, unsigned long long offset, hipStream_t s) {
+    MPO_CHECK(T >= 1 && T <= kMaxT && d % H == 0, "set-transformer attention: T=%d (max %d), d=%d, heads=%d", T, kMaxT, d, H);
+    const size_t lds = ((size_t)T * 3 * d + (size_t)H * T * T) * sizeof(float);
+    mha_small_fwd_kernel<<<B, 256, lds, s>>>(qkv, o, p_save, T, d, H, drop_p, seed, offset);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float* d_o, float* dqkv, int B, int T, int d, int H,
+                             hipStream_t s) {
+    MPO_CHECK(T >= 1 && T <= kMaxT && d % H == 0, "set-transformer attention: T=%d (max %d), d=%d, heads=%d", T, kMaxT, d, H);
+    const size_t lds = ((size_t)T * 4 * d + (size_t)H * T * T) * sizeof(float);
+    mha_small_bwd_kernel<<<B, 256, lds, s>>>(qkv, p_save, d_o, dqkv, T, d, H);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_pool_fwd(const float* scores, const float* x, float* w, float* h, int B, int L, int d, hipStream_t s) {
+    pool_fwd_kernel<<<B, 256, 0, s>>>(scores, x, w, h, L, d);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_pool_bwd(const float* dh, const float* x, const float* w, const float* d_ext, float* d_scores, float* dx,
+                        int B, int L, int d, hipStream_t s) {
+    pool_bwd_kernel<<<B, 256, 0, s>>>(dh, x, w, d_ext, d_scores, dx, L, d);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_head_fwd(const float* logits, float* hazards, float* survs, float* y, int B, int C, hipStream_t s) {
+    MPO_CHECK(C >= 1 && C <= kMaxC, "survival head: n_classes %d not in 1..%d", C, kMaxC);
+    head_fwd_kernel<<<(B + 63) / 64, 64, 0, s>>>(logits, hazards, survs, y, B, C);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_head_bwd(const float* hazards, const float* survs, const float* y, const float* dhz, const float* dsv,
+                        const float* dy, float* dlogits, int B, int C, hipStream_t s) {
+    MPO_CHECK(C >= 1 && C <= kMaxC, "survival head: n_classes %d not in 1..%d", C, kMaxC);
+    head_bwd_kernel<<<(B + 63) / 64, 64, 0, s>>>(hazards, survs, y, dhz, dsv, dy, dlogits, B, C);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_ew_mul(const float* a, const float* b, float* out, int n, hipStream_t s) {
+    ew_mul_kernel<<<(n + 255) / 256, 256, 0, s>>>(a, b, out, n);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_ew_add(const float* a, const float* b, float* out, int n, hipStream_t s) {
+    ew_add_kernel<<<(n + 255) / 256, 256, 0, s>>>(a, b, out, n);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_cag_mid_fwd(const float* u1, const float* u2, const float* u3, const float* gw, const float* gb, const float* ew,
+                           const float* eb, float* t1, float* t3, float* gout, float* eout, float* m, float* stats_g, float* stats_e,
+                           int rows, int d, float eps, hipStream_t s) {
+    cag_mid_fwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(u1, u2, u3, gw, gb, ew, eb, t1, t3, gout, eout, m, stats_g, stats_e, rows, d, eps);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_cag_mid_bwd(const float* dm, const float* t1, const float* t3, const float* gout, const float* eout,
+                           const float* gw, const float* ew, const float* stats_g, const float* stats_e, float* dG, float* dE,
+                           float* ds12, float* ds3, int rows, int d, hipStream_t s) {
+    cag_mid_bwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(dm, t1, t3, gout, eout, gw, ew, stats_g, stats_e, dG, dE, ds12, ds3, rows, d);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}

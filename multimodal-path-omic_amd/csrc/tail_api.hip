@@ -1,0 +1,358 @@
+// C-ABI entries of the 6 x d token tail (declared in include/mpo_hip.h): K3 Contextual Attention Gate,
+// K4 set-Transformer encoder, K5 gated attention-MIL pooling, K6 fusion + survival head.
+// Each entry is a fixed sequence of launches (GEMMs with fused epilogues/gates + the kernels of tail.hip)
+// on the caller's stream, in caller-provided buffers.
+#include <type_traits>
+
+#include "../../include/mpo_hip.h"
+#include "mpo_common.h"
+#include "mpo_kernels.h"
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+struct Arena {
+    char* base;
+    size_t size, off = 0;
+    Arena(void* p, size_t n) : base(static_cast<char*>(p)), size(n) {}
+    float* floats(size_t n) {
+        const size_t o = align_up(off, 256);
+        if (o + n * 4 > size) return nullptr;
+        off = o + n * 4;
+        return reinterpret_cast<float*>(base + o);
+    }
+};
+struct Sizer {                         // mirrors Arena to size a workspace
+    size_t off = 0;
+    void floats(size_t n) { off = align_up(off, 256) + n * 4; }
+};
+// carve the saved buffer sequentially (floats, 64-float aligned so float4 accesses stay aligned)
+struct Carver {
+    float* p;
+    explicit Carver(float* base) : p(base) {}
+    float* take(size_t n) { float* r = p; p += (n + 63) / 64 * 64; return r; }
+};
+struct CarveSizer {
+    size_t n = 0;
+    float* take(size_t k) { n += (k + 63) / 64 * 64; return nullptr; }
+};
+
+inline DropSpec stream_of(float p, uint64_t seed, uint64_t base, uint64_t stride, int k) {
+    DropSpec d;
+    d.p = p; d.seed = seed; d.off = base + stride * (uint64_t)k;
+    return d;
+}
+inline GateSpec gate(const float* g, int mode, float p = 0.f) {
+    GateSpec s;
+    s.g = g; s.mode = mode; s.p = p;
+    return s;
+}
+inline GateSpec gate_rng(DropSpec d) {
+    GateSpec s;
+    s.mode = d.p > 0.f ? MPO_GATE_RNG : MPO_GATE_NONE; s.p = d.p; s.seed = d.seed; s.off = d.off;
+    return s;
+}
+
+#define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+// ------------------------------------------------------------------------------------------- K4 encoder
+enum { P_INW, P_INB, P_OUTW, P_OUTB, P_L1W, P_L1B, P_L2W, P_L2B, P_N1W, P_N1B, P_N2W, P_N2B, P_PER_LAYER };
+
+struct EncLayerSaved {
+    float *qkv, *psave, *o, *s1, *st1, *x1, *f, *s2, *st2, *x2;
+};
+template <typename C>
+void enc_carve(C& c, EncLayerSaved* out, int B, int T, int d, int ff, int H) {
+    const size_t R = (size_t)B * T;
+    EncLayerSaved s;
+    s.qkv = c.take(R * 3 * d); s.psave = c.take((size_t)B * 2 * H * T * T); s.o = c.take(R * d);
+    s.s1 = c.take(R * d); s.st1 = c.take(2 * R); s.x1 = c.take(R * d); s.f = c.take(R * ff);
+    s.s2 = c.take(R * d); s.st2 = c.take(2 * R); s.x2 = c.take(R * d);
+    if (out) *out = s;
+}
+inline uint64_t enc_stream_stride(int B, int T, int d, int ff) {
+    const uint64_t R = (uint64_t)B * T;
+    const uint64_t m = R * (uint64_t)(ff > 3 * d ? ff : 3 * d);
+    return m / 4 + 2;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mpo_encoder_saved_floats(int n_slides, int T, int d, int ff, int heads, int layers) {
+    CarveSizer c;
+    for (int l = 0; l < layers; ++l) enc_carve(c, (EncLayerSaved*)nullptr, n_slides, T, d, ff, heads);
+    return c.n;
+}
+size_t mpo_encoder_workspace_bytes(int n_slides, int T, int d, int ff) {
+    const size_t R = (size_t)n_slides * T;
+    Sizer s;
+    s.floats(R * d); s.floats(R * d); s.floats(R * ff); s.floats(R * d); s.floats(R * 3 * d);
+    return s.off + 256;
+}
+uint64_t mpo_encoder_rng_span(int n_slides, int T, int d, int ff, int layers) {
+    return enc_stream_stride(n_slides, T, d, ff) * 4 * (uint64_t)layers;
+}
+
+// nn.TransformerEncoder (post-norm layers, ReLU FFN, no final norm): models/mcat/mcat.py:51-53,101-102;
+// layer arithmetic torch/nn/modules/transformer.py:661 (norm_first=False).
+int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
+                        const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                        float* y, float* saved, mpo_stream_t stream) {
+    MPO_CHECK(n_slides >= 1 && layers >= 1 && d % heads == 0, "encoder: bad geometry (slides %d, layers %d, d %d, heads %d)",
+              n_slides, layers, d, heads);
+    const int R = n_slides * T;
+    const uint64_t stride = enc_stream_stride(n_slides, T, d, ff);
+    Carver c(saved);
+    const float* in = x;
+    for (int l = 0; l < layers; ++l) {
+        const float* const* P = params + l * P_PER_LAYER;
+        EncLayerSaved S;
+        enc_carve(c, &S, n_slides, T, d, ff, heads);
+        const uint64_t base = offset + stride * 4 * (uint64_t)l;
+        const DropSpec d0 = stream_of(drop_p, seed, base, stride, 0), d1 = stream_of(drop_p, seed, base, stride, 1),
+                       d2 = stream_of(drop_p, seed, base, stride, 2), d3 = stream_of(drop_p, seed, base, stride, 3);
+        RC(mpo_linear_fwd(in, P[P_INW], P[P_INB], S.qkv, R, d, 3 * d, 1.0f, MPO_ACT_NONE, stream));
+        RC(mpo_launch_mha_small_fwd(S.qkv, S.o, S.psave, n_slides, T, d, heads, d0.p, d0.seed, d0.off, stream));
+        RC(mpo_linear_fwd(S.o, P[P_OUTW], P[P_OUTB], S.s1, R, d, d, 1.0f, MPO_ACT_NONE, stream, in, d1));
+        RC(mpo_launch_ln_fwd(S.s1, P[P_N1W], P[P_N1B], S.x1, S.st1, R, d, 1e-5f, stream));
+        RC(mpo_linear_fwd(S.x1, P[P_L1W], P[P_L1B], S.f, R, d, ff, 1.0f, MPO_ACT_RELU, stream, nullptr, d2));
+        RC(mpo_linear_fwd(S.f, P[P_L2W], P[P_L2B], S.s2, R, ff, d, 1.0f, MPO_ACT_NONE, stream, S.x1, d3));
+        float* out = (l == layers - 1) ? y : S.x2;
+        RC(mpo_launch_ln_fwd(S.s2, P[P_N2W], P[P_N2B], out, S.st2, R, d, 1e-5f, stream));
+        in = out;
+    }
+    return 0;
+}
+
+int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
+                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                         const float* saved, const float* dy, float* dx, float* const* grads,
+                         void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    const int R = n_slides * T;
+    const uint64_t stride = enc_stream_stride(n_slides, T, d, ff);
+    Arena ws(workspace, workspace_bytes);
+    float* ga = ws.floats((size_t)R * d);
+    float* gb = ws.floats((size_t)R * d);
+    float* df = ws.floats((size_t)R * ff);
+    float* dob = ws.floats((size_t)R * d);
+    float* dqkv = ws.floats((size_t)R * 3 * d);
+    MPO_CHECK(ga && gb && df && dob && dqkv, "encoder backward: workspace too small (%zu bytes)", workspace_bytes);
+    EncLayerSaved S[8];
+    MPO_CHECK(layers <= 8, "encoder: at most 8 layers (got %d)", layers);
+    Carver c(const_cast<float*>(saved));
+    for (int l = 0; l < layers; ++l) enc_carve(c, &S[l], n_slides, T, d, ff, heads);
+    const float* dcur = dy;
+    for (int l = layers - 1; l >= 0; --l) {
+        const float* const* P = params + l * P_PER_LAYER;
+        float* const* G = grads + l * P_PER_LAYER;
+        const float* in = l == 0 ? x : S[l - 1].x2;
+        const uint64_t base = offset + stride * 4 * (uint64_t)l;
+        const DropSpec d1 = stream_of(drop_p, seed, base, stride, 1), d3 = stream_of(drop_p, seed, base, stride, 3);
+        // x2 = LN2(s2)
+        RC(mpo_launch_ln_bwd(dcur, S[l].s2, S[l].st2, P[P_N2W], ga, G[P_N2W], G[P_N2B], R, d, 0, stream));     // ga = ds2
+        // s2 = x1 + drop3(f W2^T + b2)
+        RC(mpo_linear_bwd_input(ga, P[P_L2W], df, R, ff, d, 1.0f, 0, stream, gate_rng(d3)));                     // df
+        RC(mpo_linear_bwd_weight(ga, S[l].f, G[P_L2W], G[P_L2B], R, ff, d, 1.0f, stream, gate_rng(d3)));
+        // f = drop2(relu(x1 W1^T + b1));  dx1 = ds2 + (df*gate) W1   (accumulated in place into ga)
+        RC(mpo_linear_bwd_input(df, P[P_L1W], ga, R, d, ff, 1.0f, 1, stream, gate(S[l].f, MPO_GATE_RELU, drop_p)));
+        RC(mpo_linear_bwd_weight(df, S[l].x1, G[P_L1W], G[P_L1B], R, d, ff, 1.0f, stream, gate(S[l].f, MPO_GATE_RELU, drop_p)));
+        // x1 = LN1(s1)
+        RC(mpo_launch_ln_bwd(ga, S[l].s1, S[l].st1, P[P_N1W], gb, G[P_N1W], G[P_N1B], R, d, 0, stream));        // gb = ds1
+        // s1 = in + drop1(o W_o^T + b_o)
+        RC(mpo_linear_bwd_input(gb, P[P_OUTW], dob, R, d, d, 1.0f, 0, stream, gate_rng(d1)));
+        RC(mpo_linear_bwd_weight(gb, S[l].o, G[P_OUTW], G[P_OUTB], R, d, d, 1.0f, stream, gate_rng(d1)));
+        RC(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, n_slides, T, d, heads, stream));
+        // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in  (accumulated in place into gb)
+        RC(mpo_linear_bwd_input(dqkv, P[P_INW], gb, R, d, 3 * d, 1.0f, 1, stream));
+        RC(mpo_linear_bwd_weight(dqkv, in, G[P_INW], G[P_INB], R, d, 3 * d, 1.0f, stream));
+        if (l == 0) {
+            MPO_HIP(hipMemcpyAsync(dx, gb, (size_t)R * d * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        } else {
+            dcur = gb;      // the layer below reads its upstream gradient from gb; its first LN-backward writes ga
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- K5 gated pooling
+// params: attention_a.0.weight, .bias, attention_b.0.weight, .bias, attention_c.weight, .bias, rho.0.weight, .bias
+// saved: a [R,d] | b [R,d] | ab [R,d] | w [R] | hpool [B,d]
+size_t mpo_gated_pool_saved_floats(int n_slides, int L, int d) {
+    CarveSizer c;
+    const size_t R = (size_t)n_slides * L;
+    c.take(R * d); c.take(R * d); c.take(R * d); c.take(R); c.take((size_t)n_slides * d);
+    return c.n;
+}
+size_t mpo_gated_pool_workspace_bytes(int n_slides, int L, int d) {
+    const size_t R = (size_t)n_slides * L;
+    Sizer s;
+    s.floats((size_t)n_slides * d); s.floats(R); s.floats(R * d); s.floats(R * d); s.floats(R * d);
+    return s.off + 256;
+}
+uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d) { return 3 * ((uint64_t)n_slides * L * d / 4 + 2); }
+
+// AttentionNetGated (models/blocks.py:13-48) + the pooling idiom of models/mcat/mcat.py:105-109:
+// scores = W_c[drop(tanh(W_a x)) * drop(sigmoid(W_b x))] + b_c; h = drop(relu(W_rho (softmax_L(scores) x) + b_rho))
+int mpo_gated_pool_forward(const float* x, int n_slides, int L, int d, const float* const* P,
+                           float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset,
+                           float* scores, float* h, float* saved, mpo_stream_t stream) {
+    const int R = n_slides * L;
+    const uint64_t stride = (uint64_t)R * d / 4 + 2;
+    Carver c(saved);
+    float* a = c.take((size_t)R * d); float* b = c.take((size_t)R * d); float* ab = c.take((size_t)R * d);
+    float* w = c.take(R); float* hpool = c.take((size_t)n_slides * d);
+    RC(mpo_linear_fwd(x, P[0], P[1], a, R, d, d, 1.0f, MPO_ACT_TANH, stream, nullptr, stream_of(head_drop_p, seed, offset, stride, 0)));
+    RC(mpo_linear_fwd(x, P[2], P[3], b, R, d, d, 1.0f, MPO_ACT_SIGMOID, stream, nullptr, stream_of(head_drop_p, seed, offset, stride, 1)));
+    RC(mpo_launch_ew_mul(a, b, ab, R * d, stream));
+    RC(mpo_linear_fwd(ab, P[4], P[5], scores, R, d, 1, 1.0f, MPO_ACT_NONE, stream));
+    RC(mpo_launch_pool_fwd(scores, x, w, hpool, n_slides, L, d, stream));
+    RC(mpo_linear_fwd(hpool, P[6], P[7], h, n_slides, d, d, 1.0f, MPO_ACT_RELU, stream, nullptr, stream_of(rho_drop_p, seed, offset, stride, 2)));
+    return 0;
+}
+
+int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const float* const* P,
+                            float head_drop_p, float rho_drop_p, const float* saved, const float* h,
+                            const float* dh, const float* d_scores_ext, float* dx, float* const* G,
+                            void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    const int R = n_slides * L;
+    Carver c(const_cast<float*>(saved));
+    const float* a = c.take((size_t)R * d); const float* b = c.take((size_t)R * d); const float* ab = c.take((size_t)R * d);
+    const float* w = c.take(R); const float* hpool = c.take((size_t)n_slides * d);
+    Arena ws(workspace, workspace_bytes);
+    float* dhpool = ws.floats((size_t)n_slides * d);
+    float* dscores = ws.floats(R);
+    float* dab = ws.floats((size_t)R * d);
+    float* da = ws.floats((size_t)R * d);
+    float* db = ws.floats((size_t)R * d);
+    MPO_CHECK(dhpool && dscores && dab && da && db, "gated pool backward: workspace too small (%zu bytes)", workspace_bytes);
+    // h = drop(relu(hpool W_rho^T + b_rho))
+    RC(mpo_linear_bwd_input(dh, P[6], dhpool, n_slides, d, d, 1.0f, 0, stream, gate(h, MPO_GATE_RELU, rho_drop_p)));
+    RC(mpo_linear_bwd_weight(dh, hpool, G[6], G[7], n_slides, d, d, 1.0f, stream, gate(h, MPO_GATE_RELU, rho_drop_p)));
+    RC(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, n_slides, L, d, stream));
+    // scores = ab W_c^T + b_c
+    RC(mpo_linear_bwd_input(dscores, P[4], dab, R, d, 1, 1.0f, 0, stream));
+    RC(mpo_linear_bwd_weight(dscores, ab, G[4], G[5], R, d, 1, 1.0f, stream));
+    RC(mpo_launch_ew_mul(dab, b, da, R * d, stream));
+    RC(mpo_launch_ew_mul(dab, a, db, R * d, stream));
+    RC(mpo_linear_bwd_input(da, P[0], dx, R, d, d, 1.0f, 1, stream, gate(a, MPO_GATE_TANH, head_drop_p)));
+    RC(mpo_linear_bwd_weight(da, x, G[0], G[1], R, d, d, 1.0f, stream, gate(a, MPO_GATE_TANH, head_drop_p)));
+    RC(mpo_linear_bwd_input(db, P[2], dx, R, d, d, 1.0f, 1, stream, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
+    RC(mpo_linear_bwd_weight(db, x, G[2], G[3], R, d, d, 1.0f, stream, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- K6 fusion + head
+// params: fusion_layer.0.weight, .bias, fusion_layer.2.weight, .bias, classifier.weight, .bias
+// saved: z1 [B,hidden] | z2 [B,dout] | logits [B,C]
+size_t mpo_fusion_head_saved_floats(int n_slides, int hidden, int dout, int n_classes) {
+    CarveSizer c;
+    c.take((size_t)n_slides * hidden); c.take((size_t)n_slides * dout); c.take((size_t)n_slides * n_classes);
+    return c.n;
+}
+size_t mpo_fusion_head_workspace_bytes(int n_slides, int hidden, int dout, int n_classes) {
+    Sizer s;
+    s.floats((size_t)n_slides * n_classes); s.floats((size_t)n_slides * dout); s.floats((size_t)n_slides * hidden);
+    return s.off + 256;
+}
+
+// ConcatFusion (models/fusion.py:7-19) on the concatenated [h_path | h_omic], classifier and the
+// survival head of models/mcat/mcat.py:126-138.
+int mpo_fusion_head_forward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
+                            const float* const* P, float* hazards, float* survs, float* y, float* saved,
+                            mpo_stream_t stream) {
+    Carver c(saved);
+    float* z1 = c.take((size_t)n_slides * hidden); float* z2 = c.take((size_t)n_slides * dout);
+    float* logits = c.take((size_t)n_slides * n_classes);
+    RC(mpo_linear_fwd(hcat, P[0], P[1], z1, n_slides, din, hidden, 1.0f, MPO_ACT_RELU, stream));
+    RC(mpo_linear_fwd(z1, P[2], P[3], z2, n_slides, hidden, dout, 1.0f, MPO_ACT_RELU, stream));
+    RC(mpo_linear_fwd(z2, P[4], P[5], logits, n_slides, dout, n_classes, 1.0f, MPO_ACT_NONE, stream));
+    RC(mpo_launch_head_fwd(logits, hazards, survs, y, n_slides, n_classes, stream));
+    return 0;
+}
+
+int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
+                             const float* const* P, const float* saved, const float* hazards, const float* survs,
+                             const float* y, const float* d_hazards, const float* d_survs, const float* d_y,
+                             float* d_hcat, float* const* G, void* workspace, size_t workspace_bytes,
+                             mpo_stream_t stream) {
+    Carver c(const_cast<float*>(saved));
+    const float* z1 = c.take((size_t)n_slides * hidden); const float* z2 = c.take((size_t)n_slides * dout);
+    Arena ws(workspace, workspace_bytes);
+    float* dlogits = ws.floats((size_t)n_slides * n_classes);
+    float* dz2 = ws.floats((size_t)n_slides * dout);
+    float* dz1 = ws.floats((size_t)n_slides * hidden);
+    MPO_CHECK(dlogits && dz2 && dz1, "fusion head backward: workspace too small (%zu bytes)", workspace_bytes);
+    RC(mpo_launch_head_bwd(hazards, survs, y, d_hazards, d_survs, d_y, dlogits, n_slides, n_classes, stream));
+    RC(mpo_linear_bwd_input(dlogits, P[4], dz2, n_slides, dout, n_classes, 1.0f, 0, stream));
+    RC(mpo_linear_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f, stream));
+    RC(mpo_linear_bwd_input(dz2, P[2], dz1, n_slides, hidden, dout, 1.0f, 0, stream, gate(z2, MPO_GATE_RELU)));
+    RC(mpo_linear_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, stream, gate(z2, MPO_GATE_RELU)));
+    RC(mpo_linear_bwd_input(dz1, P[0], d_hcat, n_slides, din, hidden, 1.0f, 0, stream, gate(z1, MPO_GATE_RELU)));
+    RC(mpo_linear_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, stream, gate(z1, MPO_GATE_RELU)));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- K3 CAG
+// params: fc1.0.weight,.bias, fc2.0.weight,.bias, fc3.0.weight,.bias, G.1.weight,.bias, E.1.weight,.bias, fc_c.0.weight,.bias
+// saved: u1 u2 u3 t1 t3 G E m  [R,h each] | stats_g [R,2] | stats_e [R,2]
+size_t mpo_cag_saved_floats(int rows, int hidden) {
+    CarveSizer c;
+    for (int i = 0; i < 8; ++i) c.take((size_t)rows * hidden);
+    c.take(2 * (size_t)rows); c.take(2 * (size_t)rows);
+    return c.n;
+}
+size_t mpo_cag_workspace_bytes(int rows, int hidden) {
+    Sizer s;
+    for (int i = 0; i < 5; ++i) s.floats((size_t)rows * hidden);
+    return s.off + 256;
+}
+
+// ContextualAttentionGate.forward, models/blocks.py:247-253
+int mpo_cag_forward(const float* q, const float* q_hat, int rows, int dim, int hidden, const float* const* P,
+                    float* c_out, float* saved, mpo_stream_t stream) {
+    Carver c(saved);
+    float* u1 = c.take((size_t)rows * hidden); float* u2 = c.take((size_t)rows * hidden); float* u3 = c.take((size_t)rows * hidden);
+    float* t1 = c.take((size_t)rows * hidden); float* t3 = c.take((size_t)rows * hidden);
+    float* g = c.take((size_t)rows * hidden); float* e = c.take((size_t)rows * hidden); float* m = c.take((size_t)rows * hidden);
+    float* sg = c.take(2 * (size_t)rows); float* se = c.take(2 * (size_t)rows);
+    RC(mpo_linear_fwd(q, P[0], P[1], u1, rows, dim, hidden, 1.0f, MPO_ACT_ELU, stream));
+    RC(mpo_linear_fwd(q_hat, P[2], P[3], u2, rows, dim, hidden, 1.0f, MPO_ACT_ELU, stream));
+    RC(mpo_linear_fwd(q_hat, P[4], P[5], u3, rows, dim, hidden, 1.0f, MPO_ACT_ELU, stream));
+    RC(mpo_launch_cag_mid_fwd(u1, u2, u3, P[6], P[7], P[8], P[9], t1, t3, g, e, m, sg, se, rows, hidden, 1e-5f, stream));
+    RC(mpo_linear_fwd(m, P[10], P[11], c_out, rows, hidden, hidden, 1.0f, MPO_ACT_ELU, stream));
+    return 0;
+}
+
+int mpo_cag_backward(const float* q, const float* q_hat, int rows, int dim, int hidden, const float* const* P,
+                     const float* saved, const float* c_out, const float* d_c, float* d_q, float* d_q_hat,
+                     float* const* G, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    Carver c(const_cast<float*>(saved));
+    const float* u1 = c.take((size_t)rows * hidden); const float* u2 = c.take((size_t)rows * hidden);
+    const float* u3 = c.take((size_t)rows * hidden); const float* t1 = c.take((size_t)rows * hidden);
+    const float* t3 = c.take((size_t)rows * hidden); const float* g = c.take((size_t)rows * hidden);
+    const float* e = c.take((size_t)rows * hidden); const float* m = c.take((size_t)rows * hidden);
+    const float* sg = c.take(2 * (size_t)rows); const float* se = c.take(2 * (size_t)rows);
+    Arena ws(workspace, workspace_bytes);
+    float* dm = ws.floats((size_t)rows * hidden); float* dG = ws.floats((size_t)rows * hidden);
+    float* dE = ws.floats((size_t)rows * hidden); float* ds12 = ws.floats((size_t)rows * hidden);
+    float* ds3 = ws.floats((size_t)rows * hidden);
+    MPO_CHECK(dm && dG && dE && ds12 && ds3, "CAG backward: workspace too small (%zu bytes)", workspace_bytes);
+    // C = ELU(m Wc^T + bc)
+    RC(mpo_linear_bwd_input(d_c, P[10], dm, rows, hidden, hidden, 1.0f, 0, stream, gate(c_out, MPO_GATE_ELU)));
+    RC(mpo_linear_bwd_weight(d_c, m, G[10], G[11], rows, hidden, hidden, 1.0f, stream, gate(c_out, MPO_GATE_ELU)));
+    RC(mpo_launch_cag_mid_bwd(dm, t1, t3, g, e, P[6], P[8], sg, se, dG, dE, ds12, ds3, rows, hidden, stream));
+    RC(mpo_launch_ln_bwd_params_only(dG, t1, sg, G[6], G[7], rows, hidden, stream));
+    RC(mpo_launch_ln_bwd_params_only(dE, t3, se, G[8], G[9], rows, hidden, stream));
+    // u1 = ELU(fc1 q), u2 = ELU(fc2 qh), u3 = ELU(fc3 qh)
+    RC(mpo_linear_bwd_input(ds12, P[0], d_q, rows, dim, hidden, 1.0f, 0, stream, gate(u1, MPO_GATE_ELU)));
+    RC(mpo_linear_bwd_weight(ds12, q, G[0], G[1], rows, dim, hidden, 1.0f, stream, gate(u1, MPO_GATE_ELU)));
+    RC(mpo_linear_bwd_input(ds12, P[2], d_q_hat, rows, dim, hidden, 1.0f, 0, stream, gate(u2, MPO_GATE_ELU)));
+    RC(mpo_linear_bwd_weight(ds12, q_hat, G[2], G[3], rows, dim, hidden, 1.0f, stream, gate(u2, MPO_GATE_ELU)));
+    RC(mpo_linear_bwd_input(ds3, P[4], d_q_hat, rows, dim, hidden, 1.0f, 1, stream, gate(u3, MPO_GATE_ELU)));
+    RC(mpo_linear_bwd_weight(ds3, q_hat, G[4], G[5], rows, dim, hidden, 1.0f, stream, gate(u3, MPO_GATE_ELU)));
+    return 0;
+}
+
+}  // extern "C"

@@ -74,23 +74,12 @@ class _FusionModelBase(nn.Module):
         """omics: per group a (B, d_i) tensor -> G_bag (B, N, d)."""
         return torch.stack([g(o.float()) for g, o in zip(self.G, omics)], dim=1)
 
-    def _pool(self, tokens, head, rho):
-        """(B, L, d) -> raw scores (B, 1, L), pooled embedding (B, d)  (models/mcat/mcat.py:105-109)."""
-        a = head.scores(tokens).transpose(1, 2)                       # (B, 1, L)
-        h = torch.bmm(torch.softmax(a, dim=2), tokens).squeeze(1)     # (B, d)
-        h = F.dropout(ops.linear(h, rho[0].weight, rho[0].bias, "relu"), rho[2].p, self.training)
-        return a, h
-
     def _tail(self, h_coattn, g_bag):
         path = self.path_transformer(h_coattn)
         omic = self.omic_transformer(g_bag)
-        a_path, h_path = self._pool(path, self.path_attention_head, self.path_rho)
-        a_omic, h_omic = self._pool(omic, self.omic_attention_head, self.omic_rho)
-        h = self.fusion_layer(h_path, h_omic)
-        logits = ops.linear(h, self.classifier.weight, self.classifier.bias)   # (B, C)
-        hazards = torch.sigmoid(logits)
-        survs = torch.cumprod(1 - hazards, dim=1)
-        y = torch.softmax(logits, dim=1)
+        a_path, h_path = ops.gated_pool(path, self.path_attention_head, self.path_rho, self.training)
+        a_omic, h_omic = ops.gated_pool(omic, self.omic_attention_head, self.omic_rho, self.training)
+        hazards, survs, y = ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
         return hazards, survs, y, a_path, a_omic
 
     # ---- window API

@@ -173,13 +173,22 @@ def coattn_mcat(query, batch: BagBatch, in_w, in_b, out_w, out_b, need_weights: 
 
 
 # ------------------------------------------------------------------------------------ tail (6 x d tokens per slide)
-# The linears below run on the HIP fp32-MFMA GEMM; the element-wise glue between them is being
-# moved into fused HIP kernels family by family (K3..K6).
 import torch.nn.functional as F  # noqa: E402
 
 
+def _reserve(span: int):
+    """Reserve `span` Philox counters for one C-ABI call's dropout streams."""
+    global _rng_calls
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    off = _rng_calls
+    _rng_calls += int(span) + 1
+    return seed, off
+
+
 def gated_scores(x, wa, ba, wb, bb, wc, bc, drop_p: float):
-    """AttentionNetGated scores (models/blocks.py:42-47): x (..., L, D) -> (..., L, n_classes)."""
+    """AttentionNetGated scores alone (models/blocks.py:42-47), for the module's stand-alone forward():
+    HIP GEMMs (fused tanh / sigmoid) + the element-wise product.  x (..., L, D) -> (..., L, n_classes).
+    The model path uses gated_pool(), which fuses scorer, pooling and rho in one C-ABI call."""
     a = linear(x, wa, ba, "tanh")
     b = linear(x, wb, bb, "sigmoid")
     if drop_p > 0.0:
@@ -188,38 +197,190 @@ def gated_scores(x, wa, ba, wb, bb, wc, bc, drop_p: float):
     return linear(a * b, wc, bc)
 
 
+class _ParamFn(torch.autograd.Function):
+    """Shared plumbing: parameters arrive as *args tensors and leave as one gradient per tensor."""
+
+
+class CagFn(torch.autograd.Function):
+    """K3: ContextualAttentionGate (models/blocks.py:247-253), one C-ABI call each way."""
+
+    @staticmethod
+    def forward(ctx, q, q_hat, *params):
+        lib = L.lib()
+        q, q_hat = q.contiguous(), q_hat.contiguous()
+        rows, dim = q.shape
+        hidden = params[0].shape[0]
+        c = torch.empty(rows, hidden, device=q.device, dtype=torch.float32)
+        saved = torch.empty(lib.mpo_cag_saved_floats(rows, hidden), device=q.device, dtype=torch.float32)
+        pa = L.ptr_array(params)
+        L.check(lib.mpo_cag_forward(L.ptr(q), L.ptr(q_hat), rows, dim, hidden, pa, L.ptr(c), L.ptr(saved),
+                                    L.stream_of(q)), "mpo_cag_forward")
+        ctx.save_for_backward(q, q_hat, c, saved, *params)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        lib = L.lib()
+        q, q_hat, c, saved, *params = ctx.saved_tensors
+        rows, dim = q.shape
+        hidden = params[0].shape[0]
+        dq, dqh = torch.empty_like(q), torch.empty_like(q_hat)
+        grads = [torch.empty_like(p) for p in params]
+        ws = _workspace(lib.mpo_cag_workspace_bytes(rows, hidden), q.device)
+        pa, ga = L.ptr_array(params), L.ptr_array(grads)
+        L.check(lib.mpo_cag_backward(L.ptr(q), L.ptr(q_hat), rows, dim, hidden, pa, L.ptr(saved), L.ptr(c),
+                                     L.ptr(dc.contiguous()), L.ptr(dq), L.ptr(dqh), ga, L.ptr(ws), ws.numel(),
+                                     L.stream_of(q)), "mpo_cag_backward")
+        return (dq, dqh, *grads)
+
+
 def contextual_gate(q, q_hat, cag):
-    """ContextualAttentionGate.forward (models/blocks.py:247-253) on (R, D) rows."""
-    g = F.elu(linear(q, cag.fc1[0].weight, cag.fc1[0].bias, "elu") + linear(q_hat, cag.fc2[0].weight, cag.fc2[0].bias, "elu"))
-    g = F.layer_norm(g, g.shape[-1:], cag.G[1].weight, cag.G[1].bias, cag.G[1].eps)
-    e = F.elu(linear(q_hat, cag.fc3[0].weight, cag.fc3[0].bias, "elu"))
-    e = F.layer_norm(e, e.shape[-1:], cag.E[1].weight, cag.E[1].bias, cag.E[1].eps)
-    return linear(g * e, cag.fc_c[0].weight, cag.fc_c[0].bias, "elu")
+    return CagFn.apply(q, q_hat, cag.fc1[0].weight, cag.fc1[0].bias, cag.fc2[0].weight, cag.fc2[0].bias,
+                       cag.fc3[0].weight, cag.fc3[0].bias, cag.G[1].weight, cag.G[1].bias,
+                       cag.E[1].weight, cag.E[1].bias, cag.fc_c[0].weight, cag.fc_c[0].bias)
 
 
-def encoder_layer(x, layer, training: bool):
-    """One post-norm TransformerEncoderLayer on x (B, T, d) (torch/nn/modules/transformer.py:661)."""
-    sa = layer.self_attn
+class EncoderFn(torch.autograd.Function):
+    """K4: the whole post-norm nn.TransformerEncoder over (n_slides, T, d) tokens."""
+
+    @staticmethod
+    def forward(ctx, x, geom, drop_p, *params):
+        lib = L.lib()
+        n_slides, T, d, ff, heads, layers = geom
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        saved = torch.empty(lib.mpo_encoder_saved_floats(n_slides, T, d, ff, heads, layers), device=x.device,
+                            dtype=torch.float32)
+        seed, off = _reserve(lib.mpo_encoder_rng_span(n_slides, T, d, ff, layers)) if drop_p > 0 else (0, 0)
+        pa = L.ptr_array(params)
+        L.check(lib.mpo_encoder_forward(L.ptr(x), n_slides, T, d, ff, heads, layers, pa, float(drop_p), seed, off,
+                                        L.ptr(y), L.ptr(saved), L.stream_of(x)), "mpo_encoder_forward")
+        ctx.save_for_backward(x, saved, *params)
+        ctx.geom, ctx.drop = geom, (float(drop_p), seed, off)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        x, saved, *params = ctx.saved_tensors
+        n_slides, T, d, ff, heads, layers = ctx.geom
+        drop_p, seed, off = ctx.drop
+        dx = torch.empty_like(x)
+        grads = [torch.empty_like(p) for p in params]
+        ws = _workspace(lib.mpo_encoder_workspace_bytes(n_slides, T, d, ff), x.device)
+        pa, ga = L.ptr_array(params), L.ptr_array(grads)
+        L.check(lib.mpo_encoder_backward(L.ptr(x), n_slides, T, d, ff, heads, layers, pa, drop_p, seed, off,
+                                         L.ptr(saved), L.ptr(dy.contiguous()), L.ptr(dx), ga, L.ptr(ws), ws.numel(),
+                                         L.stream_of(x)), "mpo_encoder_backward")
+        return (dx, None, None, *grads)
+
+
+def encoder(x, layers, training: bool):
+    """x (B, T, d) through a stack of nn.TransformerEncoderLayer parameter holders."""
     b, t, d = x.shape
-    h = sa.num_heads
-    p = layer.dropout.p if training else 0.0
-    qkv = linear(x, sa.in_proj_weight, sa.in_proj_bias).view(b, t, 3, h, d // h)
-    q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
-    s = torch.softmax(q @ k.transpose(-1, -2) / float(d // h) ** 0.5, dim=-1)
-    if p > 0.0:
-        s = F.dropout(s, p, True)
-    o = (s @ v).transpose(1, 2).reshape(b, t, d)
-    o = linear(o, sa.out_proj.weight, sa.out_proj.bias)
-    if p > 0.0:
-        o = F.dropout(o, p, True)
-    x = F.layer_norm(x + o, (d,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-    f = linear(x, layer.linear1.weight, layer.linear1.bias, "relu")
-    if p > 0.0:
-        f = F.dropout(f, p, True)
-    f = linear(f, layer.linear2.weight, layer.linear2.bias)
-    if p > 0.0:
-        f = F.dropout(f, p, True)
-    return F.layer_norm(x + f, (d,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+    l0 = layers[0]
+    params = []
+    for ly in layers:
+        params += [ly.self_attn.in_proj_weight, ly.self_attn.in_proj_bias, ly.self_attn.out_proj.weight,
+                   ly.self_attn.out_proj.bias, ly.linear1.weight, ly.linear1.bias, ly.linear2.weight, ly.linear2.bias,
+                   ly.norm1.weight, ly.norm1.bias, ly.norm2.weight, ly.norm2.bias]
+    geom = (b, t, d, l0.linear1.out_features, l0.self_attn.num_heads, len(layers))
+    y = EncoderFn.apply(x.reshape(b * t, d), geom, l0.dropout.p if training else 0.0, *params)
+    return y.view(b, t, d)
+
+
+class GatedPoolFn(torch.autograd.Function):
+    """K5: gated attention-MIL scorer + softmax pooling + rho, one C-ABI call each way."""
+
+    @staticmethod
+    def forward(ctx, x, geom, head_p, rho_p, *params):
+        lib = L.lib()
+        n_slides, Lr, d = geom
+        x = x.contiguous()
+        scores = torch.empty(n_slides * Lr, device=x.device, dtype=torch.float32)
+        h = torch.empty(n_slides, d, device=x.device, dtype=torch.float32)
+        saved = torch.empty(lib.mpo_gated_pool_saved_floats(n_slides, Lr, d), device=x.device, dtype=torch.float32)
+        seed, off = _reserve(lib.mpo_gated_pool_rng_span(n_slides, Lr, d)) if (head_p > 0 or rho_p > 0) else (0, 0)
+        pa = L.ptr_array(params)
+        L.check(lib.mpo_gated_pool_forward(L.ptr(x), n_slides, Lr, d, pa, float(head_p), float(rho_p), seed, off,
+                                           L.ptr(scores), L.ptr(h), L.ptr(saved), L.stream_of(x)),
+                "mpo_gated_pool_forward")
+        ctx.save_for_backward(x, saved, h, *params)
+        ctx.geom, ctx.drop = geom, (float(head_p), float(rho_p))
+        return scores, h
+
+    @staticmethod
+    def backward(ctx, d_scores, dh):
+        lib = L.lib()
+        x, saved, h, *params = ctx.saved_tensors
+        n_slides, Lr, d = ctx.geom
+        head_p, rho_p = ctx.drop
+        dx = torch.empty_like(x)
+        grads = [torch.empty_like(p) for p in params]
+        if dh is None:
+            dh = torch.zeros_like(h)
+        ws = _workspace(lib.mpo_gated_pool_workspace_bytes(n_slides, Lr, d), x.device)
+        pa, ga = L.ptr_array(params), L.ptr_array(grads)
+        L.check(lib.mpo_gated_pool_backward(L.ptr(x), n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h),
+                                            L.ptr(dh.contiguous()),
+                                            L.ptr(d_scores.contiguous()) if d_scores is not None else None,
+                                            L.ptr(dx), ga, L.ptr(ws), ws.numel(), L.stream_of(x)),
+                "mpo_gated_pool_backward")
+        return (dx, None, None, None, *grads)
+
+
+def gated_pool(tokens, head, rho, training: bool):
+    """tokens (B, L, d) -> raw scores (B, 1, L), pooled embedding (B, d)   (models/mcat/mcat.py:105-109)."""
+    b, l, d = tokens.shape
+    if head.attention_c.weight.shape[0] != 1 or head.attention_a[0].weight.shape != (d, d):
+        raise NotImplementedError("gated pooling kernel: n_classes=1 and hidden_dim == input_dim only")
+    params = (head.attention_a[0].weight, head.attention_a[0].bias, head.attention_b[0].weight, head.attention_b[0].bias,
+              head.attention_c.weight, head.attention_c.bias, rho[0].weight, rho[0].bias)
+    scores, h = GatedPoolFn.apply(tokens.reshape(b * l, d), (b, l, d), head.drop_p if training else 0.0,
+                                  rho[2].p if training else 0.0, *params)
+    return scores.view(b, 1, l), h
+
+
+class FusionHeadFn(torch.autograd.Function):
+    """K6: concat-fusion MLP + classifier + survival head."""
+
+    @staticmethod
+    def forward(ctx, hcat, *params):
+        lib = L.lib()
+        hcat = hcat.contiguous()
+        b, din = hcat.shape
+        hidden, dout, c = params[0].shape[0], params[2].shape[0], params[4].shape[0]
+        hz = torch.empty(b, c, device=hcat.device, dtype=torch.float32)
+        sv, y = torch.empty_like(hz), torch.empty_like(hz)
+        saved = torch.empty(lib.mpo_fusion_head_saved_floats(b, hidden, dout, c), device=hcat.device, dtype=torch.float32)
+        pa = L.ptr_array(params)
+        L.check(lib.mpo_fusion_head_forward(L.ptr(hcat), b, din, hidden, dout, c, pa, L.ptr(hz), L.ptr(sv), L.ptr(y),
+                                            L.ptr(saved), L.stream_of(hcat)), "mpo_fusion_head_forward")
+        ctx.save_for_backward(hcat, saved, hz, sv, y, *params)
+        return hz, sv, y
+
+    @staticmethod
+    def backward(ctx, dhz, dsv, dy):
+        lib = L.lib()
+        hcat, saved, hz, sv, y, *params = ctx.saved_tensors
+        b, din = hcat.shape
+        hidden, dout, c = params[0].shape[0], params[2].shape[0], params[4].shape[0]
+        d_hcat = torch.empty_like(hcat)
+        grads = [torch.empty_like(p) for p in params]
+        ws = _workspace(lib.mpo_fusion_head_workspace_bytes(b, hidden, dout, c), hcat.device)
+        pa, ga = L.ptr_array(params), L.ptr_array(grads)
+        opt = lambda t: L.ptr(t.contiguous()) if t is not None else None  # noqa: E731
+        L.check(lib.mpo_fusion_head_backward(L.ptr(hcat), b, din, hidden, dout, c, pa, L.ptr(saved), L.ptr(hz), L.ptr(sv),
+                                             L.ptr(y), opt(dhz), opt(dsv), opt(dy), L.ptr(d_hcat), ga, L.ptr(ws),
+                                             ws.numel(), L.stream_of(hcat)), "mpo_fusion_head_backward")
+        return (d_hcat, *grads)
+
+
+def fusion_head(h_path, h_omic, fusion_layer, classifier):
+    """(B,d),(B,d) -> hazards, survs, Y (B, C)   (models/fusion.py:17-19 + models/mcat/mcat.py:126-138)."""
+    seq = fusion_layer.fusion_layer
+    return FusionHeadFn.apply(torch.cat([h_path, h_omic], dim=-1), seq[0].weight, seq[0].bias, seq[2].weight,
+                              seq[2].bias, classifier.weight, classifier.bias)
 
 
 # ------------------------------------------------------------------------------------ K2

@@ -23,8 +23,7 @@ class SetTransformerEncoder(nn.TransformerEncoder):
         if mask is not None or src_key_padding_mask is not None:
             raise NotImplementedError("masks are never used on this path")
         x = src if src.dim() == 3 else src.unsqueeze(0)
-        for layer in self.layers:
-            x = ops.encoder_layer(x, layer, self.training)
+        x = ops.encoder(x, list(self.layers), self.training)
         return x if src.dim() == 3 else x[0]
 
 

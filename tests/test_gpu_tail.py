@@ -1,0 +1,142 @@
+"""GPU parity of the token-tail kernels (rows H5-H8: K3 CAG is in test_gpu_coattn_nacagat.py, here
+K4 set-Transformer, K5 gated attention-MIL pooling, K6 fusion + survival head) against the
+reference's golden vectors, plus training-mode consistency of forward and backward dropout masks."""
+import pytest
+import torch
+import torch.nn as nn
+
+import cases as C
+from multimodal_path_omic_amd import ops
+from multimodal_path_omic_amd import synthetic as syn
+from multimodal_path_omic_amd.blocks import AttentionNetGated
+from multimodal_path_omic_amd.fusion import ConcatFusion
+from multimodal_path_omic_amd.transformer import make_set_transformer
+
+pytestmark = pytest.mark.gpu
+sub = syn.subsample
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def check_grads(g, prefix, names, grads, tol=2e-3):
+    for n, gr in zip(names, grads):
+        ref = g[prefix + n]
+        scale = max(float(ref.abs().max()), 1e-5)
+        err = float((sub(gr).cpu() - ref).abs().max()) / scale
+        assert err < tol, (n, err)
+
+
+def test_encoder_matches_golden(dev, golden):
+    g = golden("encoder")
+    sd = syn.fill_state_dict(C.encoder_shapes("path_transformer"), 600)
+    enc = make_set_transformer(C.E, 0.25)
+    enc.load_state_dict({k[len("path_transformer."):]: v for k, v in sd.items()}, strict=True)
+    enc.to(dev).eval()
+    x, probe = C.encoder_inputs()
+    xd = x.to(dev).requires_grad_(True)
+    y = enc(xd)                                             # (T, d): the reference's unbatched call
+    assert relerr(y, g["y"]) < 1e-4
+    params = dict(enc.named_parameters())
+    tensors = [xd] + [params[k[len("path_transformer."):]] for k in sd]
+    grads = torch.autograd.grad((y * probe.to(dev)).sum(), tensors)
+    check_grads(g, "grad/", ["x"] + list(sd), grads)
+    # a window of slides: every slide gets the single-slide result
+    xb = torch.stack([x, 2 * x, -x]).to(dev)
+    yb = enc(xb)
+    assert relerr(yb[0], y) < 1e-5 and relerr(yb[1], enc(2 * x.to(dev))) < 1e-5
+
+
+@pytest.mark.parametrize("case", list(C.POOL_CASES))
+def test_gated_pool_matches_golden(dev, golden, case):
+    g = golden("pool")
+    l, seed = C.POOL_CASES[case]
+    sd = syn.fill_state_dict(C.pool_shapes("path_attention_head", "path_rho"), seed)
+    head = AttentionNetGated(n_classes=1, input_dim=C.E, hidden_dim=C.E)
+    rho = nn.Sequential(nn.Linear(C.E, C.E), nn.ReLU(), nn.Dropout(0.25))
+    head.load_state_dict({k[len("path_attention_head."):]: v for k, v in sd.items() if k.startswith("path_attention_head.")})
+    rho.load_state_dict({k[len("path_rho."):]: v for k, v in sd.items() if k.startswith("path_rho.")})
+    head.to(dev).eval(); rho.to(dev).eval()
+    x, probe_h, probe_a = C.pool_inputs(l, seed + 1)
+    xd = x.to(dev).requires_grad_(True)
+    a, h = ops.gated_pool(xd.unsqueeze(0), head, rho, training=False)
+    assert relerr(a[0], g[f"{case}/A"]) < 1e-4
+    assert relerr(h[0], g[f"{case}/h"]) < 1e-4
+    # the module's stand-alone forward() keeps the reference signature: (A (L,1), x)
+    a2, x2 = head(xd)
+    assert a2.shape == (l, 1) and x2 is xd and relerr(a2.t(), g[f"{case}/A"]) < 1e-4
+    hp, rp = dict(head.named_parameters()), dict(rho.named_parameters())
+    names = ["x"] + list(sd)
+    tensors = [xd] + [hp[k[len("path_attention_head."):]] if k.startswith("path_attention_head.") else rp[k[len("path_rho."):]]
+                      for k in sd]
+    loss = (h[0] * probe_h.to(dev)).sum() + (a[0] * probe_a.to(dev)).sum()
+    check_grads(g, f"{case}/grad/", names, torch.autograd.grad(loss, tensors))
+
+
+def test_fusion_head_matches_golden(dev, golden):
+    g = golden("fusion")
+    sd = syn.fill_state_dict(C.FUSION_SHAPES, 700)
+    fus = ConcatFusion(dims=[C.E, C.E], hidden_size=C.E, output_size=C.E)
+    cls = nn.Linear(C.E, 4)
+    fus.load_state_dict({k[len("fusion_layer."):]: v for k, v in sd.items() if k.startswith("fusion_layer.")})
+    cls.load_state_dict({k[len("classifier."):]: v for k, v in sd.items() if k.startswith("classifier.")})
+    fus.to(dev); cls.to(dev)
+    hp, ho, probe = C.fusion_inputs()
+    hpd, hod = hp.to(dev).requires_grad_(True), ho.to(dev).requires_grad_(True)
+    assert relerr(fus(hpd, hod), g["h"]) < 1e-4             # stand-alone ConcatFusion.forward(*x)
+    hz, sv, y = ops.fusion_head(hpd.unsqueeze(0), hod.unsqueeze(0), fus, cls)
+    for t, k in ((hz, "hazards"), (sv, "survs"), (y, "Y")):
+        assert float((t.cpu() - g[k]).abs().max()) < 1e-5
+    p = probe.to(dev)
+    loss = (hz * p).sum() + (sv * p.flip(1)).sum() + (y * p * 0.5).sum()
+    fp, cp = dict(fus.named_parameters()), dict(cls.named_parameters())
+    names = ["h_path", "h_omic"] + list(sd)
+    tensors = [hpd, hod] + [fp[k[len("fusion_layer."):]] if k.startswith("fusion_layer.") else cp[k[len("classifier."):]]
+                            for k in sd]
+    check_grads(g, "grad/", names, torch.autograd.grad(loss, tensors))
+
+
+def _directional(fn, x, v, eps=1e-2):
+    return (fn(x + eps * v) - fn(x - eps * v)) / (2 * eps)
+
+
+@pytest.mark.parametrize("which", ["encoder", "pool"])
+def test_training_dropout_forward_backward_use_the_same_masks(dev, which):
+    """With the Philox counter pinned, the forward is a deterministic function of its input, so the
+    analytic gradient (masks regenerated in backward) must match a finite difference."""
+    torch.manual_seed(5)
+    gsyn = syn.rng(31)
+    b, t = 3, C.N_OMIC
+    x = syn.normal(gsyn, (b, t, C.E)).to(dev)
+    v = syn.normal(gsyn, (b, t, C.E)).to(dev)
+    probe = syn.normal(gsyn, (b, t, C.E)).to(dev)
+    if which == "encoder":
+        mod = make_set_transformer(C.E, 0.25).to(dev).train()
+
+        def f(inp):
+            ops._rng_calls = 1234
+            return (mod(inp) * probe).sum().double()
+    else:
+        head = AttentionNetGated(n_classes=1, input_dim=C.E, hidden_dim=C.E).to(dev).train()
+        rho = nn.Sequential(nn.Linear(C.E, C.E), nn.ReLU(), nn.Dropout(0.25)).to(dev).train()
+
+        def f(inp):
+            ops._rng_calls = 1234
+            a, h = ops.gated_pool(inp, head, rho, training=True)
+            return ((h * probe[:, 0]).sum() + a.sum() * 0.1).double()
+    xr = x.clone().requires_grad_(True)
+    out = f(xr)
+    out.backward()
+    ana = float((xr.grad * v).sum())
+    num = float(_directional(f, x, v))
+    assert abs(ana - num) < 5e-2 * max(1.0, abs(num)), (ana, num)
+    # dropout is really on: another counter gives another value
+    ops._rng_calls = 99999
+    other = float((mod(x) * probe).sum()) if which == "encoder" else float(ops.gated_pool(x, head, rho, True)[1].sum())
+    ops._rng_calls = 1234
+    same = float((mod(x) * probe).sum()) if which == "encoder" else float(ops.gated_pool(x, head, rho, True)[1].sum())
+    ops._rng_calls = 99999
+    again = float((mod(x) * probe).sum()) if which == "encoder" else float(ops.gated_pool(x, head, rho, True)[1].sum())
+    assert other == again and other != same
