@@ -56,7 +56,7 @@ _SIGNATURES = {
     "mpo_fusion_head_saved_floats": (c_size_t, [c_int] * 4),
     "mpo_fusion_head_workspace_bytes": (c_size_t, [c_int] * 4),
     "mpo_fusion_head_forward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P, _P, _P]),
-    "mpo_fusion_head_backward": (c_int, [_P] + [c_int] * 5 + [_P] * 10 + [c_size_t, _P]),
+    "mpo_fusion_head_backward": (c_int, [_P] + [c_int] * 5 + [_P] * 11 + [c_size_t, _P]),
     "mpo_cag_saved_floats": (c_size_t, [c_int] * 2),
     "mpo_cag_workspace_bytes": (c_size_t, [c_int] * 2),
     "mpo_cag_forward": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -102,5 +102,5 @@ def test_window_equals_per_slide(dev, kind):
         assert relerr(att_w["coattn"][b], att["coattn"]) < 1e-4
         ces_loss(hz, sv, labels[b:b + 1], cens[b:b + 1]).backward()
     for n, p in model.named_parameters():
-        scale = max(float(p.grad.abs().max()), 1e-4)            # shift-invariant biases: ~1e-9 noise
+        scale = max(float(p.grad.abs().max()), 1e-3)            # shift-invariant biases: ~1e-8 noise
         assert float((grads_w[n] - p.grad).abs().max()) / scale < 2e-4, n
