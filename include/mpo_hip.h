@@ -76,7 +76,18 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                              float* d_query, void* d_bag,
                              float* d_in_proj_weight, float* d_in_proj_bias,
                              float* d_out_proj_weight, float* d_out_proj_bias,
-                             void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+                             float bag_relu_gate, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+/* bag_relu_gate: 0, or 1/(1-p) when the (bf16) bag is H = dropout_p(relu(.)) as in models/mcat/mcat.py:24-29,87 and
+ * the caller wants d_bag already multiplied by that epilogue's derivative (H > 0 ? 1/(1-p) : 0): the H tile is still
+ * in LDS when dH is formed, which saves two passes over the bag gradient. */
+
+/* ---- epilogue of the patch layer self.H (models/mcat/mcat.py:24-29): h = dropout_p(relu(h + bias)) in place on the
+ * bf16 GEMM output [rows, cols], and its derivative g = dy * (h > 0 ? 1/(1-p) : 0).  The GEMM itself stays a library
+ * call. */
+int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, int cols, float drop_p, uint64_t seed,
+                               uint64_t offset, mpo_stream_t stream);
+int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, float drop_p,
+                                mpo_stream_t stream);
 
 /* ---- K2: NaCAGaT narrow-gated co-attention core = models/blocks.py:114-206 (heads = 1):
  *   S = (q/sqrt(E)) k^T * (tanh(q) tanh(k)^T + 1)/2,  A = softmax(S),  A_drop = dropout(A, p) in training,

@@ -35,7 +35,9 @@ _SIGNATURES = {
     "mpo_coattn_mcat_forward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                         _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
-                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                         _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    "mpo_patch_epilogue_forward": (c_int, [_P, _P, ctypes.c_int64, c_int, c_float, c_uint64, c_uint64, _P]),
+    "mpo_patch_epilogue_backward": (c_int, [_P, _P, _P, ctypes.c_int64, c_float, _P]),
     "mpo_nacagat_saved_floats": (c_size_t, [c_int, c_int, c_int]),
     "mpo_nacagat_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "mpo_coattn_nacagat_forward": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,

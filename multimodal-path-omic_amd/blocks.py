@@ -67,11 +67,11 @@ class CoAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.in_proj_bias)
 
-    def forward_window(self, query: torch.Tensor, bags: BagBatch, need_weights: bool = False):
+    def forward_window(self, query: torch.Tensor, bags: BagBatch, need_weights: bool = False, bag_relu_gate: float = 0.0):
         """query (n_slides, N, E) -> out (n_slides, N, E), list of (N, M_b) maps or None."""
         n_slides, n_q, e = query.shape
         out, amap = ops.coattn_mcat(query.reshape(n_slides * n_q, e), bags, self.in_proj_weight, self.in_proj_bias,
-                                    self.out_proj.weight, self.out_proj.bias, need_weights)
+                                    self.out_proj.weight, self.out_proj.bias, need_weights, bag_relu_gate)
         return out.view(n_slides, n_q, e), (bags.split_map(amap, n_q) if need_weights else None)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, need_weights: bool = True,

@@ -367,7 +367,59 @@ __global__ void row_scaled_bias_kernel(float* __restrict__ y, const float* __res
     y[i] += s[i / cols] * bias[i % cols];
 }
 
+// patch-layer epilogue: h = drop(relu(h + bias)), bf16 in place, 8 elements (16 bytes) per lane
+__global__ void bias_relu_dropout_bf16_kernel(bf16x8* __restrict__ h, const float* __restrict__ bias, size_t n8, int cols,
+                                              float drop_p, unsigned long long seed, unsigned long long offset) {
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        bf16x8 v = h[i];
+        const int c0 = (int)((i * 8) % cols);
+        uint4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
+        if (drop_p > 0.f) {
+            r0 = philox4x32((uint32_t)(offset + 2 * i), (uint32_t)((offset + 2 * i) >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+            r1 = philox4x32((uint32_t)(offset + 2 * i + 1), (uint32_t)((offset + 2 * i + 1) >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        }
+        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = fmaxf((float)v[j] + bias[c0 + j], 0.f);
+            if (drop_p > 0.f) x = ((float)(rw[j] >> 8) * (1.0f / 16777216.0f) >= drop_p) ? x * inv_keep : 0.f;
+            v[j] = (__bf16)x;
+        }
+        h[i] = v;
+    }
+}
+__global__ void relu_dropout_bwd_bf16_kernel(const bf16x8* __restrict__ h, const bf16x8* __restrict__ dy, bf16x8* __restrict__ g,
+                                             size_t n8, float inv_keep) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 hv = h[i], d = dy[i];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (float)hv[j] > 0.f ? (__bf16)((float)d[j] * inv_keep) : (__bf16)0.f;
+        g[i] = o;
+    }
+}
+
 }  // namespace
+
+int mpo_launch_bias_relu_dropout_bf16(void* h, const float* bias, size_t rows, int cols, float drop_p,
+                                      unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+    MPO_CHECK(cols % 8 == 0, "patch epilogue: width %d not a multiple of 8", cols);
+    const size_t n8 = rows * (size_t)cols / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    bias_relu_dropout_bf16_kernel<<<blocks, 256, 0, stream>>>((bf16x8*)h, bias, n8, cols, drop_p, seed, offset);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, size_t n, float drop_p, hipStream_t stream) {
+    MPO_CHECK(n % 8 == 0, "patch epilogue backward: %zu elements not a multiple of 8", n);
+    const size_t n8 = n / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    relu_dropout_bwd_bf16_kernel<<<blocks, 256, 0, stream>>>((const bf16x8*)h, (const bf16x8*)dy, (bf16x8*)g, n8,
+                                                             drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
 
 // ---------------------------------------------------------------------------- host launchers
 #define MPO_E_SWITCH(embed, CALL)                                                     \

@@ -131,7 +131,7 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                              int max_rows, const float* query, int n_q, int embed, const float* in_w,
                              const float* out_w, const float* saved, const float* attn_map, const float* d_out,
                              const float* d_attn_map, float* d_query, void* d_bag, float* d_in_w, float* d_in_b,
-                             float* d_out_w, float* d_out_b, void* workspace, size_t workspace_bytes,
+                             float* d_out_w, float* d_out_b, float bag_relu_gate, void* workspace, size_t workspace_bytes,
                              mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "coattn backward: embed_dim 512 ('big') is not built yet");
@@ -168,7 +168,7 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
         if ((rc = mpo_launch_map_rowdot(attn_map, d_attn_map, cu_rows, delta, n_slides, n_q, 1, stream))) return rc;
     // the bag pass
     if ((rc = mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, E, qk2, lse2, dctx, delta, attn_map,
-                                    d_attn_map, d_bag, part_dqk, n_q, splits, stream))) return rc;
+                                    d_attn_map, d_bag, part_dqk, n_q, splits, bag_relu_gate, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part_dqk, dqk, n_slides, n_q, E, splits, stream))) return rc;
     // qk = qs W_k :  dqs = dqk W_k^T (folded with the 1/sqrt(E) of qs = scale * (...)),  dW_k = qs^T dqk,  db_k = 0
     if ((rc = mpo_linear_fwd(dqk, w_k, nullptr, dq_pre, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
@@ -322,7 +322,17 @@ int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_row
                            const float* d_attn_map, void* d_bag, float* part_dqk, int n_q, int splits,
                            mpo_stream_t stream) {
     return mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, lse2, dctx, delta, nullptr,
-                                 d_attn_map, d_bag, part_dqk, n_q, splits, stream);
+                                 d_attn_map, d_bag, part_dqk, n_q, splits, 0.f, stream);
+}
+
+// ------------------------------------------------------------------------------------------- patch layer epilogue
+int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, int cols, float drop_p, uint64_t seed,
+                               uint64_t offset, mpo_stream_t stream) {
+    return mpo_launch_bias_relu_dropout_bf16(h_bf16, bias, (size_t)rows, cols, drop_p, seed, offset, stream);
+}
+int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, float drop_p,
+                                mpo_stream_t stream) {
+    return mpo_launch_relu_dropout_bwd_bf16(h_bf16, dy_bf16, g_bf16, (size_t)n, drop_p, stream);
 }
 
 }  // extern "C"

@@ -60,7 +60,8 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                        const float* __restrict__ da_map,   // nullable, ragged [n_q][M_b] per slide
                        void* __restrict__ dbag_,           // [total_rows][E], bag dtype
                        float* __restrict__ part_dqk,       // [n_slides][splits][n_q][E] (natural units)
-                       int n_q, int splits) {
+                       int n_q, int splits,
+                       float relu_gate /* 0: off; else 1/(1-p): dH *= (H > 0 ? relu_gate : 0), bf16 bag only */) {
     using G = TileGeom<E_>;
     using C = BwdCfg<E_, F32BAG>;
     constexpr int WAVES = C::WAVES;
@@ -209,9 +210,16 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                 }
                 // lane holds dH[row][16t + 4g .. +3]
                 if constexpr (!F32BAG) {
-                    bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
                     const int c = (2 * t + (g >> 1)) ^ ((row & 7) << 1);
-                    *reinterpret_cast<bf16x4*>(thi + row * G::ROWB + (c << 4) + 8 * (g & 1)) = ob;
+                    bf16x4* slot = reinterpret_cast<bf16x4*>(thi + row * G::ROWB + (c << 4) + 8 * (g & 1));
+                    if (relu_gate != 0.f) {
+                        // the bag is H = drop(relu(pre)): the slot about to receive dH still holds H itself
+                        const bf16x4 hv = *slot;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] *= (float)hv[j] > 0.f ? relu_gate : 0.f;
+                    }
+                    bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    *slot = ob;
                 } else {
                     const int c = (4 * t + g) ^ ((row & 7) << 1);
                     *reinterpret_cast<f32x4*>(thi + row * (E_ * 4) + (c << 4)) = o;
@@ -310,17 +318,18 @@ __global__ void map_rowdot_kernel(const float* __restrict__ a_map, const float* 
 int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                           const float* qk2, const float* lse2, const float* dctx, const float* delta,
                           const float* a_map, const float* da_map,
-                          void* dbag, float* part_dqk, int n_q, int splits, hipStream_t stream) {
+                          void* dbag, float* part_dqk, int n_q, int splits, float relu_gate, hipStream_t stream) {
     (void)a_map;
+    MPO_CHECK(relu_gate == 0.f || !bag_f32, "coattn backward: the fused relu/dropout gate needs a bf16 bag");
     dim3 grid(splits, n_slides);
 #define MPO_BWD_CASE(EV)                                                                                     \
     case EV:                                                                                                 \
         if (bag_f32)                                                                                         \
             coattn_bwd_kernel<EV, true><<<grid, BwdCfg<EV, true>::WAVES * 64, 0, stream>>>(                  \
-                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, splits);                       \
+                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, splits, relu_gate);           \
         else                                                                                                 \
             coattn_bwd_kernel<EV, false><<<grid, BwdCfg<EV, false>::WAVES * 64, 0, stream>>>(                \
-                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, splits);                       \
+                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, splits, relu_gate);           \
         break;
     switch (embed) {
         MPO_BWD_CASE(128)

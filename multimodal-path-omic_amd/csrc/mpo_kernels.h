@@ -98,7 +98,7 @@ int mpo_launch_coattn_normalize(float* a, const float* lse2, const int* cu, int 
 int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                           const float* qk2, const float* lse2, const float* dctx, const float* delta,
                           const float* a_map, const float* da_map,
-                          void* dbag, float* part_dqk, int n_q, int splits, hipStream_t stream);
+                          void* dbag, float* part_dqk, int n_q, int splits, float relu_gate, hipStream_t stream);
 int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, int splits,
                                  hipStream_t stream);
 int mpo_launch_rowdot(const float* a, const float* b, float* out, int rows, int cols, hipStream_t stream);
@@ -151,3 +151,9 @@ int mpo_launch_cag_mid_fwd(const float* u1, const float* u2, const float* u3, co
 int mpo_launch_cag_mid_bwd(const float* dm, const float* t1, const float* t3, const float* gout, const float* eout,
                            const float* gw, const float* ew, const float* stats_g, const float* stats_e, float* dG, float* dE,
                            float* ds12, float* ds3, int rows, int d, hipStream_t s);
+
+// h = drop(relu(h + bias)) in place on a bf16 [rows][cols] tensor (the patch layer's epilogue)
+int mpo_launch_bias_relu_dropout_bf16(void* h, const float* bias, size_t rows, int cols, float drop_p,
+                                      unsigned long long seed, unsigned long long offset, hipStream_t stream);
+// g = dy * (h > 0 ? 1/(1-p) : 0) on bf16 tensors (derivative of the same epilogue)
+int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, size_t n, float drop_p, hipStream_t stream);

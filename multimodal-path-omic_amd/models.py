@@ -60,14 +60,17 @@ class _FusionModelBase(nn.Module):
         self.classifier = nn.Linear(d1, n_classes)
 
     # ---- pieces
+    # the co-attention kernel can hand back d(H_bag) already multiplied by the ReLU/dropout derivative
+    _fused_bag_gate = False
+
     def _patch_fc(self, bags: BagBatch) -> BagBatch:
         x = bags.data
         lin = self.H[0]
+        p = self.H[2].p if self.training else 0.0
         if x.dtype == torch.bfloat16:
-            h = F.linear(x, lin.weight.to(torch.bfloat16), lin.bias.to(torch.bfloat16))
+            h = ops.patch_fc(x, lin.weight, lin.bias, p, pre_gated_grad=self._fused_bag_gate)
         else:
-            h = F.linear(x.float(), lin.weight, lin.bias)
-        h = F.dropout(torch.relu(h), self.H[2].p, self.training)
+            h = F.dropout(torch.relu(F.linear(x.float(), lin.weight, lin.bias)), p, self.training)
         return bags.with_data(h)
 
     def _omic_fc(self, omics: "List[torch.Tensor]") -> torch.Tensor:
@@ -117,8 +120,13 @@ class MultimodalCoAttentionTransformer(_FusionModelBase):
     def _make_co_attention(self, d):
         return CoAttention(embed_dim=d, num_heads=1)
 
+    _fused_bag_gate = True
+
     def _co_attend(self, g_bag, h_bags, inference):
-        return self.co_attention.forward_window(g_bag, h_bags, need_weights=inference)
+        gate = 0.0
+        if h_bags.data.dtype == torch.bfloat16:
+            gate = 1.0 / (1.0 - self.H[2].p) if self.training else 1.0
+        return self.co_attention.forward_window(g_bag, h_bags, need_weights=inference, bag_relu_gate=gate)
 
     def forward(self, wsi, omics, inference: bool = False):
         return self._forward_one(wsi, omics, inference)

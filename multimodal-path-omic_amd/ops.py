@@ -120,8 +120,10 @@ class CoAttnMCATFn(torch.autograd.Function):
     """MCAT co-attention over a ragged window (models/mcat/mcat.py:97)."""
 
     @staticmethod
-    def forward(ctx, query, bag_data, in_w, in_b, out_w, out_b, batch: BagBatch, need_weights: bool):
+    def forward(ctx, query, bag_data, in_w, in_b, out_w, out_b, batch: BagBatch, need_weights: bool,
+                bag_relu_gate: float = 0.0):
         lib = L.lib()
+        ctx.bag_relu_gate = float(bag_relu_gate)
         n_slides = batch.n_slides
         R, E = query.shape
         n_q = R // n_slides
@@ -162,14 +164,68 @@ class CoAttnMCATFn(torch.autograd.Function):
             L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, batch.total_rows,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(out_w), L.ptr(saved), L.ptr(amap),
             L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), L.ptr(d_bag), L.ptr(d_in_w), L.ptr(d_in_b),
-            L.ptr(d_out_w), L.ptr(d_out_b), L.ptr(ws), ws.numel(), L.stream_of(query)),
+            L.ptr(d_out_w), L.ptr(d_out_b), ctx.bag_relu_gate, L.ptr(ws), ws.numel(), L.stream_of(query)),
             "mpo_coattn_mcat_backward")
-        return d_query, d_bag, d_in_w, d_in_b, d_out_w, d_out_b, None, None
+        return d_query, d_bag, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None
 
 
-def coattn_mcat(query, batch: BagBatch, in_w, in_b, out_w, out_b, need_weights: bool):
-    """query (n_slides*n_q, E) -> (out (n_slides*n_q, E), ragged map or None)."""
-    return CoAttnMCATFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, need_weights)
+def coattn_mcat(query, batch: BagBatch, in_w, in_b, out_w, out_b, need_weights: bool, bag_relu_gate: float = 0.0):
+    """query (n_slides*n_q, E) -> (out (n_slides*n_q, E), ragged map or None).
+    bag_relu_gate = 1/(1-p) when the bag comes from patch_fc(..., pre_gated_grad=True): d_bag then already
+    carries the ReLU/dropout derivative (see include/mpo_hip.h)."""
+    return CoAttnMCATFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, need_weights, bag_relu_gate)
+
+
+# ------------------------------------------------------------------------------------ patch layer (row H2)
+class PatchFcFn(torch.autograd.Function):
+    """H_bag = dropout_p(relu(X W_H^T + b)) for a bf16-stored window (models/mcat/mcat.py:24-29,87).
+
+    The two big GEMMs stay library calls (hipBLASLt through torch): forward X W^T, backward dW = g^T X.
+    What is ours: the fused bias + ReLU + dropout epilogue (one pass, mask regenerated from the Philox
+    counter instead of stored) and the contraction over ~10^5-10^6 patch rows of dW, which hipBLASLt runs
+    on 16 workgroups when given as one GEMM: it is issued as a batched split-K product (fp32 partials)
+    and summed.  X never needs a gradient (it is data)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, drop_p: float, pre_gated_grad: bool):
+        lib = L.lib()
+        h = torch.mm(x, weight.to(torch.bfloat16).t())
+        seed, off = _reserve(h.numel() // 4 + 2) if drop_p > 0 else (0, 0)
+        L.check(lib.mpo_patch_epilogue_forward(L.ptr(h), L.ptr(bias), h.shape[0], h.shape[1], float(drop_p), seed, off,
+                                               L.stream_of(h)), "mpo_patch_epilogue_forward")
+        ctx.save_for_backward(x, h)
+        ctx.drop_p, ctx.pre_gated = float(drop_p), bool(pre_gated_grad)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = L.lib()
+        x, h = ctx.saved_tensors
+        dh = dh.contiguous()
+        if ctx.pre_gated:
+            g = dh
+        else:
+            g = torch.empty_like(dh)
+            L.check(lib.mpo_patch_epilogue_backward(L.ptr(h), L.ptr(dh), L.ptr(g), g.numel(), ctx.drop_p,
+                                                    L.stream_of(g)), "mpo_patch_epilogue_backward")
+        return None, _splitk_tn(g, x), g.sum(0, dtype=torch.float32), None, None
+
+
+def _splitk_tn(g: torch.Tensor, x: torch.Tensor, target_chunk: int = 8192) -> torch.Tensor:
+    """g^T x with the (huge) row dimension split into batches: (S, d, C) @ (S, C, k) -> sum_S, fp32."""
+    rows = g.shape[0]
+    s = max(1, rows // target_chunk)
+    c = rows // s
+    main = s * c
+    part = torch.bmm(g[:main].view(s, c, -1).transpose(1, 2), x[:main].view(s, c, -1), out_dtype=torch.float32)
+    dw = part.sum(0)
+    if main < rows:
+        dw += torch.mm(g[main:].t(), x[main:], out_dtype=torch.float32)
+    return dw
+
+
+def patch_fc(x_bf16, weight, bias, drop_p: float, pre_gated_grad: bool = False):
+    return PatchFcFn.apply(x_bf16, weight, bias, drop_p, pre_gated_grad)
 
 
 # ------------------------------------------------------------------------------------ tail (6 x d tokens per slide)
