@@ -46,10 +46,19 @@ def _elu(x):
 
 
 # --------------------------------------------------------------------------- H2
-def patch_fc(wsi, p, prefix="H", keep=None):
-    """H_bag = Drop(ReLU(X W_H^T + b)); models/mcat/mcat.py:24-29,87."""
+def _store(t, dtype):
+    """Round-trip through a storage dtype (identity gradient): emulates a tensor kept in bf16."""
+    return t if dtype is None else t.to(dtype).float()
+
+
+def patch_fc(wsi, p, prefix="H", keep=None, storage=None):
+    """H_bag = Drop(ReLU(X W_H^T + b)); models/mcat/mcat.py:24-29,87.
+    storage=torch.bfloat16 emulates the product's bf16 STORAGE points (patch matrix, GEMM weight operand,
+    GEMM output, H_bag) with fp32 arithmetic in between, so a bf16-stored run can be checked tightly."""
     x = wsi.squeeze(0) if wsi.dim() == 3 else wsi
-    h = torch.relu(_lin(x.float(), p, prefix + ".0"))
+    x = _store(x.float(), storage)
+    h = _store(x @ _store(p[prefix + ".0.weight"], storage).t(), storage)
+    h = _store(torch.relu(h + p[prefix + ".0.bias"]), storage)
     return h if keep is None else h * keep
 
 
@@ -201,17 +210,17 @@ def _tail(h_coattn, g_bag, a_coattn, p):
     return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
 
 
-def mcat_forward(p, wsi, omics, inference=False):
+def mcat_forward(p, wsi, omics, inference=False, bag_storage=None):
     """MultimodalCoAttentionTransformer.forward, models/mcat/mcat.py:84-142 (eval mode)."""
-    h_bag = patch_fc(wsi, p)
+    h_bag = patch_fc(wsi, p, storage=bag_storage)
     g_bag = omic_fc(omics, p)
     h_co, a_co = mcat_coattention(g_bag, h_bag, p, need_weights=inference)
     return _tail(h_co, g_bag, a_co, p)
 
 
-def nacagat_forward(p, wsi, omics):
+def nacagat_forward(p, wsi, omics, bag_storage=None):
     """NarrowContextualAttentionGateTransformer.forward, models/nacagat/nacagat.py:80-138 (eval mode)."""
-    h_bag = patch_fc(wsi, p)
+    h_bag = patch_fc(wsi, p, storage=bag_storage)
     g_bag = omic_fc(omics, p)
     h_co, a_co = pregating_contextual_attention(g_bag, h_bag, p)
     return _tail(h_co, g_bag, a_co, p)

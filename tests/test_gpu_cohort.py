@@ -1,0 +1,59 @@
+"""Seeded synthetic-cohort run: the reference's train()/validate() loop, restated in
+multimodal-path-omic_amd/harness.py around the HIP model (dropout off, fixed slide order, fixed 80/20
+split, Adam lr 2e-4 wd 1e-5, grad_acc_step 8), must reproduce the per-slide risks the REFERENCE produced
+(tests/golden/cohort.npz) and therefore the same C-index on the fixed split."""
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+from multimodal_path_omic_amd import harness
+from multimodal_path_omic_amd import synthetic as syn
+from multimodal_path_omic_amd.dp import FlatGradBucket
+from multimodal_path_omic_amd.models import (MultimodalCoAttentionTransformer,
+                                             NarrowContextualAttentionGateTransformer)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind", ["mcat", "nacagat"])
+def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kind):
+    g = golden("cohort")
+    cfg = C.COHORT
+    slides = syn.make_cohort(cfg["n_slides"], cfg["m_lo"], cfg["m_hi"], cfg["omic_sizes"], cfg["seed"])
+    n_train = int(cfg["train_frac"] * len(slides))
+    cls = MultimodalCoAttentionTransformer if kind == "mcat" else NarrowContextualAttentionGateTransformer
+    model = cls(omic_sizes=cfg["omic_sizes"])
+    model.load_state_dict(syn.fill_state_dict(C.model_shapes(cfg["omic_sizes"], kind == "nacagat"), cfg["weight_seed"]))
+    model.to(dev).eval()                                       # dropout off, gradients on (as the generator)
+    bucket = FlatGradBucket(list(model.parameters()))
+    opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    acc = cfg["grad_acc_step"]
+    event = np.array([1 - s["censorship"] for s in slides]).astype(bool)
+    times = np.array([s["survival_months"] for s in slides])
+    for epoch in range(cfg["epochs"]):
+        risks, losses = [], []
+        for w0 in range(0, n_train, acc):                      # one window = one optimiser step
+            window = slides[w0:min(w0 + acc, n_train)]
+            bags, omics, labels, cens = harness.make_window(window, dev)
+            bucket.zero()
+            per_slide, risk = harness.train_window(model, bags, omics, labels, cens, acc)
+            opt.step()
+            risks.append(risk.cpu())
+            losses.append(per_slide.cpu())
+        risks, losses = torch.cat(risks).numpy(), torch.cat(losses).numpy()
+        ref_r, ref_l = g[f"{kind}/train_risk/{epoch}"].numpy(), g[f"{kind}/train_loss/{epoch}"].numpy()
+        assert np.abs(risks - ref_r).max() < 1e-3, np.abs(risks - ref_r).max()
+        assert np.abs(losses - ref_l).max() < 1e-3
+        with torch.no_grad():
+            bags, omics, _, _ = harness.make_window(slides[n_train:], dev)
+            _, sv, _, _ = model.forward_window(bags, omics)
+            val = harness.risk_score(sv).cpu().numpy()
+        ref_v = g[f"{kind}/val_risk/{epoch}"].numpy()
+        assert np.abs(val - ref_v).max() < 1e-3
+        ci = harness.concordance_index_censored(event[:n_train], times[:n_train], risks)
+        ci_ref = harness.concordance_index_censored(event[:n_train], times[:n_train], ref_r)
+        assert ci == pytest.approx(ci_ref, abs=1e-12)
+        civ = harness.concordance_index_censored(event[n_train:], times[n_train:], val)
+        civ_ref = harness.concordance_index_censored(event[n_train:], times[n_train:], ref_v)
+        assert civ == pytest.approx(civ_ref, abs=1e-12)

@@ -76,18 +76,20 @@ def test_model_bf16_bag_within_north_star(dev, kind):
     hz_o, sv_o, y_o, _ = fwd(sd, wsi, omics)
     assert float((hz.cpu() - hz_o).abs().max()) < 1e-3
     assert float((sv.cpu() - sv_o).abs().max()) < 1e-3
-    # gradients through the bf16 patch layer (split-K dW, ReLU gate fused into the co-attention backward):
-    # bf16-sized agreement with the fp32 oracle
+    # Gradients: bf16 is a STORAGE format, so the oracle is fed the same stored values (patch matrix, H-layer
+    # GEMM operands/output, H_bag rounded to bf16; fp32 arithmetic) and must then agree closely.  What remains
+    # is the bf16 rounding of d(H_bag) on its way into dW_H.
     label, censor = torch.tensor([2]), torch.tensor([0.0])
     ces_loss(hz, sv, label.to(dev), censor.to(dev)).backward()
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    hz_o, sv_o, _, _ = fwd(p, wsi, omics)
-    O.ces_loss(hz_o, sv_o, label, censor).backward()
+    hz_s, sv_s, _, _ = fwd(p, wsi, omics, bag_storage=torch.bfloat16)
+    assert float((hz.cpu() - hz_s).abs().max()) < 2e-4
+    O.ces_loss(hz_s, sv_s, label, censor).backward()
     for n, prm in model.named_parameters():
         ref = p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])
         scale = max(float(ref.abs().max()), 1e-4)
         err = float((prm.grad.cpu() - ref).abs().max()) / scale
-        assert err < (6e-2 if n.startswith("H.") or "co_attention" in n else 3e-2), (n, err)
+        assert err < (2e-2 if n.startswith("H.") else 1e-2), (n, err)
 
 
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])
