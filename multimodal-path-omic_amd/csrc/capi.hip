@@ -3,6 +3,7 @@
 // only in caller-provided buffers.  No allocation, no synchronisation, graph-capturable.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/mpo_hip.h"
 #include "mpo_common.h"
@@ -35,7 +36,8 @@ static inline size_t arena_need(size_t acc, size_t n_floats) { return align_up(a
 
 extern "C" int mpo_coattn_splits(int n_slides, int max_rows) {
     // ~4 workgroups per CU over the window; at least one 32-row tile per wave of a workgroup
-    int s = (1024 + n_slides - 1) / n_slides;
+    static const int target = [] { const char* e = getenv("MPO_COATTN_TARGET_WGS"); return e ? atoi(e) : 1024; }();
+    int s = (target + n_slides - 1) / n_slides;
     if (s > 512) s = 512;
     const int cap = (max_rows + 127) / 128;
     if (s > cap) s = cap;

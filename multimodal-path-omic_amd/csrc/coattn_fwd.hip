@@ -115,25 +115,53 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
     float* s_row = (s_out != nullptr) ? s_out + (size_t)n_q * row_begin + (size_t)q * m_rows : nullptr;
     const char* slide = reinterpret_cast<const char*>(bag_) + (size_t)row_begin * E_ * (F32BAG ? 4 : 2);
 
-    Stage<E_, F32BAG> st0;
-    Stage<E_, F32BAG> st1;                                        // second half of an fp32 tile
-    if (n_my > 0) {
-        st0.load(slide, r0 + kTileRows * wave, m_rows, 0, lane);
-        if constexpr (F32BAG) st1.load(slide, r0 + kTileRows * wave, m_rows, 1, lane);
-    }
-    for (int it = 0; it < n_my; ++it) {
-        const int trow = r0 + kTileRows * (wave + it * WAVES);
-        st0.store(thi, tlo, 0, lane);
-        if constexpr (F32BAG) st1.store(thi, tlo, 1, lane);
-        if (it + 1 < n_my) {                                      // next tile's loads fly under this tile's MFMAs
-            st0.load(slide, trow + kTileRows * WAVES, m_rows, 0, lane);
-            if constexpr (F32BAG) st1.load(slide, trow + kTileRows * WAVES, m_rows, 1, lane);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        fwd_tile<E_, C::NT>(thi, tlo, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
+    const int tstride = kTileRows * WAVES;
+    const int t0row = r0 + kTileRows * wave;
+    if constexpr (!F32BAG) {
+        // bf16 bag: TWO tiles in flight per wave (32 KiB), register sets alternate (static names: unrolled by 2)
+        Stage<E_, false> sa, sb;
+        if (n_my > 0) sa.load(slide, t0row, m_rows, 0, lane);
+        if (n_my > 1) sb.load(slide, t0row + tstride, m_rows, 0, lane);
+        for (int it = 0; it < n_my; it += 2) {
+            int trow = t0row + it * tstride;
+            sa.store(thi, tlo, 0, lane);
+            if (it + 2 < n_my) sa.load(slide, trow + 2 * tstride, m_rows, 0, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            fwd_tile<E_, 1>(thi, tlo, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
                             s_row ? s_row + trow : nullptr, q_live, lane);
-        __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();
+            if (it + 1 < n_my) {
+                trow += tstride;
+                sb.store(thi, tlo, 0, lane);
+                if (it + 3 < n_my) sb.load(slide, trow + 2 * tstride, m_rows, 0, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                fwd_tile<E_, 1>(thi, tlo, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
+                                s_row ? s_row + trow : nullptr, q_live, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else {
+        Stage<E_, true> st0, st1;                                 // the two 16-row halves of an fp32 tile
+        if (n_my > 0) {
+            st0.load(slide, t0row, m_rows, 0, lane);
+            st1.load(slide, t0row, m_rows, 1, lane);
+        }
+        for (int it = 0; it < n_my; ++it) {
+            const int trow = t0row + it * tstride;
+            st0.store(thi, tlo, 0, lane);
+            st1.store(thi, tlo, 1, lane);
+            if (it + 1 < n_my) {                                  // next tile's loads fly under this tile's MFMAs
+                st0.load(slide, trow + tstride, m_rows, 0, lane);
+                st1.load(slide, trow + tstride, m_rows, 1, lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            fwd_tile<E_, 2>(thi, tlo, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
+                            s_row ? s_row + trow : nullptr, q_live, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 
     // ---- merge the waves of this workgroup through LDS (each wave reuses its own image)
