@@ -35,8 +35,10 @@ struct Arena {
 static inline size_t arena_need(size_t acc, size_t n_floats) { return align_up(acc, 256) + n_floats * 4; }
 
 extern "C" int mpo_coattn_splits(int n_slides, int max_rows) {
-    // ~4 workgroups per CU over the window; at least one 32-row tile per wave of a workgroup
-    static const int target = [] { const char* e = getenv("MPO_COATTN_TARGET_WGS"); return e ? atoi(e) : 1024; }();
+    // ONE workgroup per CU over the window (256 CUs): long row ranges amortise the per-workgroup prologue
+    // (query fragments) and epilogue (LDS merge, partial write); measured r01 on 32 x 15k bf16:
+    // 256 WGs 51.6 us, 512 59.0, 1024 73.0, 2048 98.9.  At least one 32-row tile per wave of a workgroup.
+    static const int target = [] { const char* e = getenv("MPO_COATTN_TARGET_WGS"); return e ? atoi(e) : 256; }();
     int s = (target + n_slides - 1) / n_slides;
     if (s > 512) s = 512;
     const int cap = (max_rows + 127) / 128;

@@ -14,15 +14,18 @@
 // Tile: 32 x 32 outputs per 256-thread workgroup (4 waves x 16x16), and a whole K chunk of up to 256
 // staged at once: every global load of a chunk is in flight together (these GEMMs are a few hundred KB
 // and launch/latency-bound, not bandwidth-bound), the next chunk is prefetched into registers while the
-// MFMAs of the current one run.  LDS image [row][k], row stride 264 floats: the operand read is one
-// conflict-free ds_read_b128 per four MFMAs (lane (i = l&15, kq = l>>4) takes k = 16kk + 4kq + j for the
-// j-th MFMA of the block; any partition of k is valid as long as A and B agree).
+// MFMAs of the current one run.  Lane (i = l&15, kq = l>>4) takes k = 16kk + 4kq + j for the j-th MFMA of a
+// block of four (any partition of k is valid as long as A and B agree).  An operand whose k is contiguous in
+// memory is imaged [row][k] (stride 264 floats) and read with one conflict-free ds_read_b128 per four MFMAs;
+// an operand whose ROW index is contiguous is imaged as it lies, [k][row] (stride 36 floats: float4 stores,
+// no transposition, conflict-free ds_read_b32).
 #include "mpo_common.h"
 #include "mpo_kernels.h"
 
 namespace {
 
-constexpr int BM = 32, BN = 32, KC = 256, LDK = KC + 8;
+constexpr int BM = 32, BN = 32, KC = 256, LDK = KC + 8, LDM = 36;
+constexpr int IMG_FLOATS = KC * LDM > BM * LDK ? KC * LDM : BM * LDK;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -120,19 +123,23 @@ struct OperandStage {
             if (KCONTIG) {
                 *reinterpret_cast<f32x4*>(lds + (f >> 6) * LDK + ((f & 63) << 2)) = v[i];
             } else {
-                const int k = f >> 3, mn = (f & 7) << 2;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) lds[(mn + j) * LDK + k] = v[i][j];
+                *reinterpret_cast<f32x4*>(lds + (f >> 3) * LDM + ((f & 7) << 2)) = v[i];
             }
         }
+    }
+    // the four k-values of MFMA block kk for row `row` of this operand
+    __device__ __forceinline__ static f32x4 frag(const float* __restrict__ lds, int row, int kk, int kq) {
+        if (KCONTIG) return *reinterpret_cast<const f32x4*>(lds + row * LDK + 16 * kk + 4 * kq);
+        const float* p = lds + (16 * kk + 4 * kq) * LDM + row;
+        return f32x4{p[0], p[LDM], p[2 * LDM], p[3 * LDM]};
     }
 };
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256)
 void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[IMG_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[IMG_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -164,14 +171,11 @@ void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
         const int kblocks = (min(KC, g.K - k0) + 15) >> 4;
         if (g.bias_grad != nullptr && blockIdx.x == 0 && tid < BM) {
-            const float* row = As + tid * LDK;
-            for (int k = 0; k < 16 * kblocks; ++k) bsum += row[k];
+            for (int k = 0; k < 16 * kblocks; ++k) bsum += A_KC ? As[tid * LDK + k] : As[k * LDM + tid];
         }
-        const float* ap = As + (16 * wm + i16) * LDK + 4 * kq;
-        const float* bp = Bs + (16 * wn + i16) * LDK + 4 * kq;
         for (int kk = 0; kk < kblocks; ++kk) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 16 * kk);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 16 * kk);
+            const f32x4 a = OperandStage<A_KC>::frag(As, 16 * wm + i16, kk, kq);
+            const f32x4 b = OperandStage<B_KC>::frag(Bs, 16 * wn + i16, kk, kq);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
