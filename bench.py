@@ -154,17 +154,18 @@ def main():
     torch.cuda.set_device(dev)
     bag_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
-    from multimodal_path_omic_amd.dp import FlatGradBucket
+    from multimodal_path_omic_amd.dp import FlatAdam, FlatGradBucket
     from multimodal_path_omic_amd.harness import train_window
     model = build_model(a.model, dev, bag_dtype)
     bucket = FlatGradBucket(list(model.parameters()))
-    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, fused=True)   # config.yaml:57-63
+    opt = FlatAdam(bucket, lr=2e-4, weight_decay=1e-5)            # adam, lr 2e-4, wd 1e-5: config.yaml:57-63
     windows = make_windows(a.n_windows, a.window, a.patches, dev, bag_dtype, seed=1234 + rank)
 
     def step(i):
         bags, omics, labels, cens = windows[i % len(windows)]
-        bucket.zero()
+        bucket.begin()
         train_window(model, bags, omics, labels, cens, a.window)
+        bucket.finish()
         bucket.all_reduce_mean()
         opt.step()
 

@@ -89,6 +89,12 @@ int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, in
 int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, float drop_p,
                                 mpo_stream_t stream);
 
+/* ---- optimiser step of the reference's default `adam` (models/mcat/main.py:284-300: torch.optim.Adam(lr, weight_decay))
+ * over ONE flat parameter / gradient / moment buffer: g' = g + wd p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
+int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int step, mpo_stream_t stream);
+
 /* ---- K2: NaCAGaT narrow-gated co-attention core = models/blocks.py:114-206 (heads = 1):
  *   S = (q/sqrt(E)) k^T * (tanh(q) tanh(k)^T + 1)/2,  A = softmax(S),  A_drop = dropout(A, p) in training,
  *   out = (A_drop v) W_o^T + b_o,  returns (q, out, A_drop)  -- the map is post-dropout, as in the reference.

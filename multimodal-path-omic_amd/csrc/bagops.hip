@@ -374,16 +374,16 @@ __global__ void bias_relu_dropout_bf16_kernel(bf16x8* __restrict__ h, const floa
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         bf16x8 v = h[i];
         const int c0 = (int)((i * 8) % cols);
-        uint4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
-        if (drop_p > 0.f) {
-            r0 = philox4x32((uint32_t)(offset + 2 * i), (uint32_t)((offset + 2 * i) >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
-            r1 = philox4x32((uint32_t)(offset + 2 * i + 1), (uint32_t)((offset + 2 * i + 1) >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
-        }
-        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        // one Philox call per 8 elements: 16 random bits each (keep iff u16 >= p * 65536)
+        uint4 r0 = {0, 0, 0, 0};
+        if (drop_p > 0.f)
+            r0 = philox4x32((uint32_t)(offset + i), (uint32_t)((offset + i) >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t rw[4] = {r0.x, r0.y, r0.z, r0.w};
+        const uint32_t thr = (uint32_t)(drop_p * 65536.0f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float x = fmaxf((float)v[j] + bias[c0 + j], 0.f);
-            if (drop_p > 0.f) x = ((float)(rw[j] >> 8) * (1.0f / 16777216.0f) >= drop_p) ? x * inv_keep : 0.f;
+            if (drop_p > 0.f) x = (((rw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) >= thr) ? x * inv_keep : 0.f;
             v[j] = (__bf16)x;
         }
         h[i] = v;
@@ -400,7 +400,30 @@ __global__ void relu_dropout_bwd_bf16_kernel(const bf16x8* __restrict__ h, const
     }
 }
 
+// torch.optim.Adam semantics (L2 weight decay folded into the gradient), one pass over the flat buffers
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] + wd * pi;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
 }  // namespace
+
+int mpo_launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                         float wd, int step, hipStream_t stream) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    adam_flat_kernel<<<blocks, 256, 0, stream>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
 
 int mpo_launch_bias_relu_dropout_bf16(void* h, const float* bias, size_t rows, int cols, float drop_p,
                                       unsigned long long seed, unsigned long long offset, hipStream_t stream) {

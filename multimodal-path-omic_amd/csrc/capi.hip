@@ -339,4 +339,11 @@ int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g
     return mpo_launch_relu_dropout_bwd_bf16(h_bf16, dy_bf16, g_bf16, (size_t)n, drop_p, stream);
 }
 
+// ------------------------------------------------------------------------------------------- optimiser
+int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int step, mpo_stream_t stream) {
+    MPO_CHECK(step >= 1, "adam: step counts from 1 (got %d)", step);
+    return mpo_launch_adam_flat(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, stream);
+}
+
 }  // extern "C"

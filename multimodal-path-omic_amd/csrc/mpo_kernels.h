@@ -157,3 +157,6 @@ int mpo_launch_bias_relu_dropout_bf16(void* h, const float* bias, size_t rows, i
                                       unsigned long long seed, unsigned long long offset, hipStream_t stream);
 // g = dy * (h > 0 ? 1/(1-p) : 0) on bf16 tensors (derivative of the same epilogue)
 int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, size_t n, float drop_p, hipStream_t stream);
+
+int mpo_launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                         float wd, int step, hipStream_t stream);

@@ -15,7 +15,13 @@ import torch.distributed as dist
 
 
 class FlatGradBucket:
-    """One contiguous fp32 gradient buffer; every parameter's .grad is a view into it."""
+    """One contiguous fp32 gradient buffer; every parameter owns a slice (`p._mpo_grad_view`).
+
+    Per window:  begin() -> forward/backward -> finish().  begin() unsets every `p.grad`, so the HIP
+    backward entries write their parameter gradients straight into the slices (ops.grad_out) and autograd
+    adopts those views as `.grad` without an accumulate kernel; finish() copies in the few gradients that
+    came from stock torch ops and zero-fills slices of unused parameters.  A second backward before the
+    optimiser step accumulates in place into the same slices."""
 
     def __init__(self, params: Sequence[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
@@ -24,11 +30,29 @@ class FlatGradBucket:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            p._mpo_grad_view = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = p._mpo_grad_view.view(p.shape)
             off += p.numel()
+
+    def begin(self):
+        for p in self.params:
+            p.grad = None
+
+    def finish(self):
+        for p in self.params:
+            view = p._mpo_grad_view
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            else:
+                continue
+            p.grad = view.view(p.shape)
 
     def zero(self):
         self.flat.zero_()
+        for p in self.params:
+            p.grad = p._mpo_grad_view.view(p.shape)
 
     def all_reduce_mean(self, group=None):
         """Sum over ranks, divide by world size: with per-rank 1/grad_acc_step loss scaling the update
@@ -36,6 +60,33 @@ class FlatGradBucket:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas, eps, weight_decay) (the reference's default optimiser,
+    models/mcat/main.py:284-300) as ONE HIP kernel over flat buffers: parameters are re-pointed at slices of
+    a flat fp32 buffer laid out like the gradient bucket; exp_avg / exp_avg_sq are flat too."""
+
+    def __init__(self, bucket: FlatGradBucket, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.bucket, self.lr, self.betas, self.eps, self.wd = bucket, lr, betas, eps, weight_decay
+        self.flat_p = torch.empty_like(bucket.flat)
+        off = 0
+        for p in bucket.params:
+            sl = self.flat_p[off:off + p.numel()].view_as(p)
+            sl.copy_(p.data)
+            p.data = sl
+            off += p.numel()
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.t = 0
+
+    def step(self):
+        from . import _lib as L
+        self.t += 1
+        b = self.bucket
+        L.check(L.lib().mpo_adam_step_flat(L.ptr(self.flat_p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                           self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                           self.t, L.stream_of(self.flat_p)), "mpo_adam_step_flat")
 
 
 def assign_slides(lengths: Sequence[int], world_size: int) -> "List[List[int]]":

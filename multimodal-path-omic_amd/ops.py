@@ -65,6 +65,19 @@ def make_cu(lengths, device):
     return torch.tensor(cu, dtype=torch.int32).to(device, non_blocking=True)
 
 
+def grad_out(p):
+    """Where a Function's backward writes the gradient of parameter `p`.
+
+    With dp.FlatGradBucket every parameter owns a slice of ONE flat fp32 gradient buffer.  While `p.grad`
+    is still unset in this window the kernels write straight into that slice and the returned view is
+    adopted by autograd as `p.grad` (no accumulate kernel); otherwise a fresh tensor is returned and
+    autograd adds it."""
+    view = getattr(p, "_mpo_grad_view", None)
+    if view is not None and p.grad is None:
+        return view.view(p.shape)          # a FRESH alias: autograd only steals a gradient nobody else references
+    return torch.empty_like(p)
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -139,6 +152,7 @@ class CoAttnMCATFn(torch.autograd.Function):
             L.ptr(out), L.ptr(amap), L.ptr(saved), L.ptr(ws), ws.numel(), L.stream_of(query)),
             "mpo_coattn_mcat_forward")
         ctx.save_for_backward(query, bag_data, in_w, out_w, saved, amap)
+        ctx.param_refs = (in_w, in_b, out_w, out_b)
         ctx.batch = batch
         ctx.n_q = n_q
         return out, amap          # the map (if any) is differentiable: backward accepts its gradient
@@ -155,10 +169,7 @@ class CoAttnMCATFn(torch.autograd.Function):
             d_map = d_map.contiguous()
         d_query = torch.empty_like(query)
         d_bag = torch.empty_like(bag_data)
-        d_in_w = torch.empty_like(in_w)
-        d_in_b = torch.empty(3 * E, device=dev, dtype=torch.float32)
-        d_out_w = torch.empty_like(out_w)
-        d_out_b = torch.empty(E, device=dev, dtype=torch.float32)
+        d_in_w, d_in_b, d_out_w, d_out_b = (grad_out(p) for p in ctx.param_refs)
         ws = _workspace(lib.mpo_coattn_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows), dev)
         L.check(lib.mpo_coattn_mcat_backward(
             L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, batch.total_rows,
@@ -190,10 +201,11 @@ class PatchFcFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, drop_p: float, pre_gated_grad: bool):
         lib = L.lib()
         h = torch.mm(x, weight.to(torch.bfloat16).t())
-        seed, off = _reserve(h.numel() // 4 + 2) if drop_p > 0 else (0, 0)
+        seed, off = _reserve(h.numel() // 8 + 2) if drop_p > 0 else (0, 0)
         L.check(lib.mpo_patch_epilogue_forward(L.ptr(h), L.ptr(bias), h.shape[0], h.shape[1], float(drop_p), seed, off,
                                                L.stream_of(h)), "mpo_patch_epilogue_forward")
         ctx.save_for_backward(x, h)
+        ctx.param_refs = (weight, bias)
         ctx.drop_p, ctx.pre_gated = float(drop_p), bool(pre_gated_grad)
         return h
 
@@ -208,20 +220,23 @@ class PatchFcFn(torch.autograd.Function):
             g = torch.empty_like(dh)
             L.check(lib.mpo_patch_epilogue_backward(L.ptr(h), L.ptr(dh), L.ptr(g), g.numel(), ctx.drop_p,
                                                     L.stream_of(g)), "mpo_patch_epilogue_backward")
-        return None, _splitk_tn(g, x), g.sum(0, dtype=torch.float32), None, None
+        dw, db = (grad_out(p) for p in ctx.param_refs)
+        _splitk_tn(g, x, dw)
+        torch.sum(g, 0, dtype=torch.float32, out=db)
+        return None, dw, db, None, None
 
 
-def _splitk_tn(g: torch.Tensor, x: torch.Tensor, target_chunk: int = 8192) -> torch.Tensor:
+def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk: int = 8192) -> torch.Tensor:
     """g^T x with the (huge) row dimension split into batches: (S, d, C) @ (S, C, k) -> sum_S, fp32."""
     rows = g.shape[0]
     s = max(1, rows // target_chunk)
     c = rows // s
     main = s * c
     part = torch.bmm(g[:main].view(s, c, -1).transpose(1, 2), x[:main].view(s, c, -1), out_dtype=torch.float32)
-    dw = part.sum(0)
+    torch.sum(part, 0, out=out)
     if main < rows:
-        dw += torch.mm(g[main:].t(), x[main:], out_dtype=torch.float32)
-    return dw
+        out += torch.mm(g[main:].t(), x[main:], out_dtype=torch.float32)
+    return out
 
 
 def patch_fc(x_bf16, weight, bias, drop_p: float, pre_gated_grad: bool = False):
@@ -272,6 +287,7 @@ class CagFn(torch.autograd.Function):
         L.check(lib.mpo_cag_forward(L.ptr(q), L.ptr(q_hat), rows, dim, hidden, pa, L.ptr(c), L.ptr(saved),
                                     L.stream_of(q)), "mpo_cag_forward")
         ctx.save_for_backward(q, q_hat, c, saved, *params)
+        ctx.param_refs = params
         return c
 
     @staticmethod
@@ -281,7 +297,7 @@ class CagFn(torch.autograd.Function):
         rows, dim = q.shape
         hidden = params[0].shape[0]
         dq, dqh = torch.empty_like(q), torch.empty_like(q_hat)
-        grads = [torch.empty_like(p) for p in params]
+        grads = [grad_out(p) for p in ctx.param_refs]
         ws = _workspace(lib.mpo_cag_workspace_bytes(rows, hidden), q.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         L.check(lib.mpo_cag_backward(L.ptr(q), L.ptr(q_hat), rows, dim, hidden, pa, L.ptr(saved), L.ptr(c),
@@ -312,6 +328,7 @@ class EncoderFn(torch.autograd.Function):
         L.check(lib.mpo_encoder_forward(L.ptr(x), n_slides, T, d, ff, heads, layers, pa, float(drop_p), seed, off,
                                         L.ptr(y), L.ptr(saved), L.stream_of(x)), "mpo_encoder_forward")
         ctx.save_for_backward(x, saved, *params)
+        ctx.param_refs = params
         ctx.geom, ctx.drop = geom, (float(drop_p), seed, off)
         return y
 
@@ -322,7 +339,7 @@ class EncoderFn(torch.autograd.Function):
         n_slides, T, d, ff, heads, layers = ctx.geom
         drop_p, seed, off = ctx.drop
         dx = torch.empty_like(x)
-        grads = [torch.empty_like(p) for p in params]
+        grads = [grad_out(p) for p in ctx.param_refs]
         ws = _workspace(lib.mpo_encoder_workspace_bytes(n_slides, T, d, ff), x.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         L.check(lib.mpo_encoder_backward(L.ptr(x), n_slides, T, d, ff, heads, layers, pa, drop_p, seed, off,
@@ -362,6 +379,7 @@ class GatedPoolFn(torch.autograd.Function):
                                            L.ptr(scores), L.ptr(h), L.ptr(saved), L.stream_of(x)),
                 "mpo_gated_pool_forward")
         ctx.save_for_backward(x, saved, h, *params)
+        ctx.param_refs = params
         ctx.geom, ctx.drop = geom, (float(head_p), float(rho_p))
         return scores, h
 
@@ -372,7 +390,7 @@ class GatedPoolFn(torch.autograd.Function):
         n_slides, Lr, d = ctx.geom
         head_p, rho_p = ctx.drop
         dx = torch.empty_like(x)
-        grads = [torch.empty_like(p) for p in params]
+        grads = [grad_out(p) for p in ctx.param_refs]
         if dh is None:
             dh = torch.zeros_like(h)
         ws = _workspace(lib.mpo_gated_pool_workspace_bytes(n_slides, Lr, d), x.device)
@@ -413,6 +431,7 @@ class FusionHeadFn(torch.autograd.Function):
         L.check(lib.mpo_fusion_head_forward(L.ptr(hcat), b, din, hidden, dout, c, pa, L.ptr(hz), L.ptr(sv), L.ptr(y),
                                             L.ptr(saved), L.stream_of(hcat)), "mpo_fusion_head_forward")
         ctx.save_for_backward(hcat, saved, hz, sv, y, *params)
+        ctx.param_refs = params
         return hz, sv, y
 
     @staticmethod
@@ -422,7 +441,7 @@ class FusionHeadFn(torch.autograd.Function):
         b, din = hcat.shape
         hidden, dout, c = params[0].shape[0], params[2].shape[0], params[4].shape[0]
         d_hcat = torch.empty_like(hcat)
-        grads = [torch.empty_like(p) for p in params]
+        grads = [grad_out(p) for p in ctx.param_refs]
         ws = _workspace(lib.mpo_fusion_head_workspace_bytes(b, hidden, dout, c), hcat.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         opt = lambda t: L.ptr(t.contiguous()) if t is not None else None  # noqa: E731
@@ -482,6 +501,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
             L.ptr(tkbag), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
             L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_forward")
         ctx.save_for_backward(query, bag_data, kbag, tkbag, in_w, in_b, out_w, saved, score_maps, amap)
+        ctx.param_refs = (in_w, in_b, out_w, out_b)
         ctx.batch, ctx.n_q, ctx.drop = batch, n_q, (float(drop_p), seed, offset)
         return q_proj, out, amap
 
@@ -500,10 +520,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         d_k = torch.empty_like(kbag)
         d_tk = torch.empty_like(kbag)
         d_h = torch.empty_like(bag_data)
-        d_in_w = torch.empty_like(in_w)
-        d_in_b = torch.empty(3 * E, device=dev, dtype=torch.float32)
-        d_out_w = torch.empty_like(out_w)
-        d_out_b = torch.empty(E, device=dev, dtype=torch.float32)
+        d_in_w, d_in_b, d_out_w, d_out_b = (grad_out(p) for p in ctx.param_refs)
         ws = _workspace(lib.mpo_nacagat_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows, T), dev)
         L.check(lib.mpo_coattn_nacagat_backward(
             L.ptr(kbag), L.ptr(tkbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,

@@ -41,9 +41,10 @@ def _worker(rank, world, port, out):
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     lengths, slides = _slides()
     mine = assign_slides(lengths, world)[rank]
-    bucket.zero()
+    bucket.begin()
     for i in mine:
         (_loss(model, slides[i]) / len(mine)).backward()          # per-rank 1/grad_acc_step scaling
+    bucket.finish()
     bucket.all_reduce_mean()
     opt.step()
     if rank == 0:
@@ -72,11 +73,16 @@ def test_two_rank_allreduce_equals_single_process(tmp_path):
 def test_bucket_views_alias_param_grads():
     model = _model()
     bucket = FlatGradBucket(list(model.parameters()))
+    bucket.begin()
     _loss(model, torch.ones(3, 8)).backward()
+    bucket.finish()                                               # stock-torch gradients are copied into the slices
     assert bucket.flat.abs().sum() > 0
     off = 0
     for p in model.parameters():
         assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
         off += p.numel()
+    ref = bucket.flat.clone()
+    _loss(model, torch.ones(3, 8)).backward()                     # a second backward accumulates in place
+    torch.testing.assert_close(bucket.flat, 2 * ref)
     bucket.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in model.parameters())

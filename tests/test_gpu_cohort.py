@@ -9,7 +9,7 @@ import torch
 import cases as C
 from multimodal_path_omic_amd import harness
 from multimodal_path_omic_amd import synthetic as syn
-from multimodal_path_omic_amd.dp import FlatGradBucket
+from multimodal_path_omic_amd.dp import FlatAdam, FlatGradBucket
 from multimodal_path_omic_amd.models import (MultimodalCoAttentionTransformer,
                                              NarrowContextualAttentionGateTransformer)
 
@@ -27,7 +27,7 @@ def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kin
     model.load_state_dict(syn.fill_state_dict(C.model_shapes(cfg["omic_sizes"], kind == "nacagat"), cfg["weight_seed"]))
     model.to(dev).eval()                                       # dropout off, gradients on (as the generator)
     bucket = FlatGradBucket(list(model.parameters()))
-    opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    opt = FlatAdam(bucket, lr=cfg["lr"], weight_decay=cfg["weight_decay"])     # ≙ torch.optim.Adam (reference default)
     acc = cfg["grad_acc_step"]
     event = np.array([1 - s["censorship"] for s in slides]).astype(bool)
     times = np.array([s["survival_months"] for s in slides])
@@ -36,8 +36,9 @@ def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kin
         for w0 in range(0, n_train, acc):                      # one window = one optimiser step
             window = slides[w0:min(w0 + acc, n_train)]
             bags, omics, labels, cens = harness.make_window(window, dev)
-            bucket.zero()
+            bucket.begin()
             per_slide, risk = harness.train_window(model, bags, omics, labels, cens, acc)
+            bucket.finish()
             opt.step()
             risks.append(risk.cpu())
             losses.append(per_slide.cpu())
