@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--n-windows", type=int, default=2, help="distinct resident windows cycled (working set >> 256 MB L3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured HIP graph")
     return ap.parse_args()
 
 
@@ -155,19 +156,41 @@ def main():
     bag_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
     from multimodal_path_omic_amd.dp import FlatAdam, FlatGradBucket
-    from multimodal_path_omic_amd.harness import train_window
+    from multimodal_path_omic_amd.harness import GraphedWindowStep, train_window
     model = build_model(a.model, dev, bag_dtype)
     bucket = FlatGradBucket(list(model.parameters()))
     opt = FlatAdam(bucket, lr=2e-4, weight_decay=1e-5)            # adam, lr 2e-4, wd 1e-5: config.yaml:57-63
     windows = make_windows(a.n_windows, a.window, a.patches, dev, bag_dtype, seed=1234 + rank)
 
-    def step(i):
+    def eager_step(i):
         bags, omics, labels, cens = windows[i % len(windows)]
         bucket.begin()
         train_window(model, bags, omics, labels, cens, a.window)
         bucket.finish()
         bucket.all_reduce_mean()
         opt.step()
+
+    graphed, graph_note = None, "eager"
+    if not a.no_graph:
+        # forward + backward (+ Adam when there is no all-reduce to wait for) captured per resident window
+        try:
+            graphed, pool = [], None
+            for w in windows:
+                gs = GraphedWindowStep(model, bucket, w, a.window, opt=opt if world == 1 else None, pool=pool)
+                pool = gs.pool()
+                graphed.append(gs)
+            graph_note = "hipgraph(fwd+bwd+adam)" if world == 1 else "hipgraph(fwd+bwd)+eager allreduce/adam"
+        except Exception as e:                                    # same kernels either way; say so in the output
+            graphed, graph_note = None, f"eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})"
+            torch.cuda.synchronize(dev)
+
+    def step(i):
+        if graphed is None:
+            return eager_step(i)
+        graphed[i % len(graphed)]()
+        if world > 1:
+            bucket.all_reduce_mean()
+            opt.step()
 
     for i in range(a.warmup):
         step(i)
@@ -195,7 +218,7 @@ def main():
             "config": {"workload": f"{a.model.upper()} medium whole model fwd+bwd+Adam, {a.patches}x1024 {a.dtype} patch bag "
                                    f"+ 6x256 omic tokens per slide, ces loss", "slides_per_rank_per_step": a.window,
                        "global_slides_per_step": world * a.window, "patches_per_slide": a.patches,
-                       "parallelism": f"dp{world}", "resident_windows": a.n_windows},
+                       "parallelism": f"dp{world}", "resident_windows": a.n_windows, "launch": graph_note},
         }
         out["roofline"] = roofline_leg(dev, a.window, a.patches, bag_dtype)
         if world == 1 and not a.no_cpu_baseline:

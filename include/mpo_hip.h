@@ -85,7 +85,7 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
  * bf16 GEMM output [rows, cols], and its derivative g = dy * (h > 0 ? 1/(1-p) : 0).  The GEMM itself stays a library
  * call. */
 int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, int cols, float drop_p, uint64_t seed,
-                               uint64_t offset, mpo_stream_t stream);
+                               uint64_t offset, const uint64_t* rng_epoch, mpo_stream_t stream);
 int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, float drop_p,
                                 mpo_stream_t stream);
 
@@ -93,7 +93,9 @@ int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g
  * over ONE flat parameter / gradient / moment buffer: g' = g + wd p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
  * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
 int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                       float beta1, float beta2, float eps, float weight_decay, int step, mpo_stream_t stream);
+                       float beta1, float beta2, float eps, float weight_decay, int step,
+                       const int32_t* step_dev /* nullable: device-resident step count, overrides `step` */,
+                       mpo_stream_t stream);
 
 /* ---- K2: NaCAGaT narrow-gated co-attention core = models/blocks.py:114-206 (heads = 1):
  *   S = (q/sqrt(E)) k^T * (tanh(q) tanh(k)^T + 1)/2,  A = softmax(S),  A_drop = dropout(A, p) in training,
@@ -113,14 +115,14 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
                                int total_rows, int max_rows, const float* query, int n_q, int embed,
                                const float* in_proj_weight, const float* in_proj_bias,
                                const float* out_proj_weight, const float* out_proj_bias,
-                               float drop_p, uint64_t seed, uint64_t offset,
+                               float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                void* tkbag, float* q_proj, float* out, float* attn_map, float* score_maps,
                                float* saved, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype, const void* hbag, int bag_dtype,
                                 const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
                                 const float* query, int n_q, int embed,
                                 const float* in_proj_weight, const float* in_proj_bias, const float* out_proj_weight,
-                                float drop_p, uint64_t seed, uint64_t offset,
+                                float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
                                 float* d_query, void* d_kbag, void* d_tk_scratch, void* d_hbag,
@@ -130,7 +132,10 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
 
 /* ==== the 6 x d token tail.  Parameter and gradient tensors are passed as arrays of device pointers in
  * the order listed per entry (the reference's state_dict order); dropout streams are Philox counters
- * (seed, offset): pass the same pair to forward and backward, reserve *_rng_span() counters per call. ==== */
+ * (seed, offset): pass the same pair to forward and backward, reserve *_rng_span() counters per call.
+ * rng_epoch (nullable, device uint64): added x 2^40 to every stream offset inside the kernels, so a HIP graph
+ * that froze (seed, offset) at capture still draws fresh masks on every replay once the host bumps *rng_epoch
+ * as part of the graph.  Eager callers pass NULL. ==== */
 
 /* ---- K4: set-Transformer = nn.TransformerEncoder(post-norm layers, nhead, dim_feedforward, relu), no final
  * norm.  Replaces models/mcat/mcat.py:51-53,60-62 (call :101-102); torch/nn/modules/transformer.py:661.
@@ -140,10 +145,10 @@ size_t mpo_encoder_saved_floats(int n_slides, int T, int d, int ff, int heads, i
 size_t mpo_encoder_workspace_bytes(int n_slides, int T, int d, int ff);
 uint64_t mpo_encoder_rng_span(int n_slides, int T, int d, int ff, int layers);
 int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
-                        const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                        const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                         float* y, float* saved, mpo_stream_t stream);
 int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
-                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                          const float* saved, const float* dy, float* dx, float* const* grads,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
@@ -154,7 +159,7 @@ size_t mpo_gated_pool_saved_floats(int n_slides, int L, int d);
 size_t mpo_gated_pool_workspace_bytes(int n_slides, int L, int d);
 uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d);
 int mpo_gated_pool_forward(const float* x, int n_slides, int L, int d, const float* const* params,
-                           float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset,
+                           float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                            float* scores, float* h, float* saved, mpo_stream_t stream);
 int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const float* const* params,
                             float head_drop_p, float rho_drop_p, const float* saved, const float* h,

@@ -36,25 +36,25 @@ _SIGNATURES = {
                                         _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
-    "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
-    "mpo_patch_epilogue_forward": (c_int, [_P, _P, ctypes.c_int64, c_int, c_float, c_uint64, c_uint64, _P]),
+    "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
+    "mpo_patch_epilogue_forward": (c_int, [_P, _P, ctypes.c_int64, c_int, c_float, c_uint64, c_uint64, _P, _P]),
     "mpo_patch_epilogue_backward": (c_int, [_P, _P, _P, ctypes.c_int64, c_float, _P]),
     "mpo_nacagat_saved_floats": (c_size_t, [c_int, c_int, c_int]),
     "mpo_nacagat_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "mpo_coattn_nacagat_forward": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
-                                           c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                           c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_nacagat_backward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
-                                            c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P,
+                                            c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P,
                                             _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_encoder_saved_floats": (c_size_t, [c_int] * 6),
     "mpo_encoder_workspace_bytes": (c_size_t, [c_int] * 4),
     "mpo_encoder_rng_span": (c_uint64, [c_int] * 5),
-    "mpo_encoder_forward": (c_int, [_P] + [c_int] * 6 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P]),
-    "mpo_encoder_backward": (c_int, [_P] + [c_int] * 6 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_encoder_forward": (c_int, [_P] + [c_int] * 6 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P]),
+    "mpo_encoder_backward": (c_int, [_P] + [c_int] * 6 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_gated_pool_saved_floats": (c_size_t, [c_int] * 3),
     "mpo_gated_pool_workspace_bytes": (c_size_t, [c_int] * 3),
     "mpo_gated_pool_rng_span": (c_uint64, [c_int] * 3),
-    "mpo_gated_pool_forward": (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, c_uint64, c_uint64, _P, _P, _P, _P]),
+    "mpo_gated_pool_forward": (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P]),
     "mpo_gated_pool_backward": (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_fusion_head_saved_floats": (c_size_t, [c_int] * 4),
     "mpo_fusion_head_workspace_bytes": (c_size_t, [c_int] * 4),

@@ -258,8 +258,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __global__ __launch_bounds__(256)
 void gated_softmax_fwd_kernel(const float* __restrict__ amap_a, const float* __restrict__ gmap, const int* __restrict__ cu,
                               float* __restrict__ out_map, float* __restrict__ lse2, float* __restrict__ asum,
-                              int n_q, float drop_p, unsigned long long seed, unsigned long long offset) {
+                              int n_q, float drop_p, unsigned long long seed, unsigned long long offset_,
+                              const unsigned long long* epoch) {
     __shared__ float red[4];
+    const unsigned long long offset = epoch_offset(offset_, epoch);
     const int q = blockIdx.x, b = blockIdx.y;
     const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
     const size_t base = (size_t)n_q * row_begin + (size_t)q * m_rows;
@@ -294,8 +296,9 @@ void gated_softmax_bwd_kernel(const float* __restrict__ amap_a, const float* __r
                               const float* __restrict__ lse2, const float* __restrict__ dasum,
                               const float* __restrict__ d_ext, float* __restrict__ da_map /* in: dctx.H, out: ds1 */,
                               float* __restrict__ dg_map, int n_q, float drop_p, unsigned long long seed,
-                              unsigned long long offset) {
+                              unsigned long long offset_, const unsigned long long* epoch) {
     __shared__ float red[4];
+    const unsigned long long offset = epoch_offset(offset_, epoch);
     const int q = blockIdx.x, b = blockIdx.y;
     const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
     const size_t base = (size_t)n_q * row_begin + (size_t)q * m_rows;
@@ -369,8 +372,10 @@ __global__ void row_scaled_bias_kernel(float* __restrict__ y, const float* __res
 
 // patch-layer epilogue: h = drop(relu(h + bias)), bf16 in place, 8 elements (16 bytes) per lane
 __global__ void bias_relu_dropout_bf16_kernel(bf16x8* __restrict__ h, const float* __restrict__ bias, size_t n8, int cols,
-                                              float drop_p, unsigned long long seed, unsigned long long offset) {
+                                              float drop_p, unsigned long long seed, unsigned long long offset_,
+                                              const unsigned long long* epoch) {
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const unsigned long long offset = epoch_offset(offset_, epoch);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         bf16x8 v = h[i];
         const int c0 = (int)((i * 8) % cols);
@@ -402,7 +407,13 @@ __global__ void relu_dropout_bwd_bf16_kernel(const bf16x8* __restrict__ h, const
 
 // torch.optim.Adam semantics (L2 weight decay folded into the gradient), one pass over the flat buffers
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                 size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                 size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                 const int* __restrict__ step_dev) {
+    if (step_dev) {                                     // graph replay: the step count lives on the device
+        const float t = (float)(*step_dev);
+        bc1 = 1.0f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float pi = p[i];
         const float gi = g[i] + wd * pi;
@@ -417,20 +428,21 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 }  // namespace
 
 int mpo_launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                         float wd, int step, hipStream_t stream) {
+                         float wd, int step, const int* step_dev, hipStream_t stream) {
     const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    adam_flat_kernel<<<blocks, 256, 0, stream>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s);
+    adam_flat_kernel<<<blocks, 256, 0, stream>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, step_dev);
     MPO_LAUNCH_CHECK();
     return 0;
 }
 
 int mpo_launch_bias_relu_dropout_bf16(void* h, const float* bias, size_t rows, int cols, float drop_p,
-                                      unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+                                      unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
+                                      hipStream_t stream) {
     MPO_CHECK(cols % 8 == 0, "patch epilogue: width %d not a multiple of 8", cols);
     const size_t n8 = rows * (size_t)cols / 8;
     const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
-    bias_relu_dropout_bf16_kernel<<<blocks, 256, 0, stream>>>((bf16x8*)h, bias, n8, cols, drop_p, seed, offset);
+    bias_relu_dropout_bf16_kernel<<<blocks, 256, 0, stream>>>((bf16x8*)h, bias, n8, cols, drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }
@@ -490,8 +502,8 @@ int mpo_launch_bag_outer(const int* cu, int n_slides, int embed, const float* w1
 
 int mpo_launch_gated_softmax_fwd(const float* amap_a, const float* gmap, const int* cu, float* out_map, float* lse2,
                                  float* asum, int n_slides, int n_q, float drop_p, unsigned long long seed,
-                                 unsigned long long offset, hipStream_t stream) {
-    gated_softmax_fwd_kernel<<<dim3(n_q, n_slides), 256, 0, stream>>>(amap_a, gmap, cu, out_map, lse2, asum, n_q, drop_p, seed, offset);
+                                 unsigned long long offset, const unsigned long long* epoch, hipStream_t stream) {
+    gated_softmax_fwd_kernel<<<dim3(n_q, n_slides), 256, 0, stream>>>(amap_a, gmap, cu, out_map, lse2, asum, n_q, drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }
@@ -499,9 +511,9 @@ int mpo_launch_gated_softmax_fwd(const float* amap_a, const float* gmap, const i
 int mpo_launch_gated_softmax_bwd(const float* amap_a, const float* gmap, const int* cu, const float* lse2,
                                  const float* dasum, const float* d_ext, float* da_map, float* dg_map, int n_slides,
                                  int n_q, float drop_p, unsigned long long seed, unsigned long long offset,
-                                 hipStream_t stream) {
+                                 const unsigned long long* epoch, hipStream_t stream) {
     gated_softmax_bwd_kernel<<<dim3(n_q, n_slides), 256, 0, stream>>>(amap_a, gmap, cu, lse2, dasum, d_ext, da_map, dg_map, n_q,
-                                                                      drop_p, seed, offset);
+                                                                      drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -205,7 +205,7 @@ size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_row
 int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,
                                int total_rows, int max_rows, const float* query, int n_q, int embed,
                                const float* in_w, const float* in_b, const float* out_w, const float* out_b,
-                               float drop_p, uint64_t seed, uint64_t offset,
+                               float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                void* tkbag, float* q_proj, float* out, float* attn_map, float* score_maps,
                                float* saved, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
@@ -233,7 +233,8 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
     if ((rc = mpo_launch_bag_tanh_fwd(kbag, tkbag, (size_t)total_rows * E, kf32, stream))) return rc;
     if ((rc = mpo_launch_bag_rowdot(kbag, kf32, cu_rows, n_slides, E, qs2, a_map, 1.0f, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_bag_rowdot(tkbag, kf32, cu_rows, n_slides, E, tq, g_map, 1.0f, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_gated_softmax_fwd(a_map, g_map, cu_rows, attn_map, lse2, asum, n_slides, n_q, drop_p, seed, offset, stream))) return rc;
+    if ((rc = mpo_launch_gated_softmax_fwd(a_map, g_map, cu_rows, attn_map, lse2, asum, n_slides, n_q, drop_p, seed, offset,
+                                           reinterpret_cast<const unsigned long long*>(rng_epoch), stream))) return rc;
     if ((rc = mpo_launch_bag_colacc(hbag, f32, cu_rows, n_slides, E, attn_map, part, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part, ctx, n_slides, n_q, E, splits, stream))) return rc;
     // attn = ctx W_v^T + (sum_m A_drop) b_v ;  out = attn W_o^T + b_o
@@ -246,7 +247,7 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
 int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype, const void* hbag, int bag_dtype,
                                 const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
                                 const float* query, int n_q, int embed, const float* in_w, const float* in_b,
-                                const float* out_w, float drop_p, uint64_t seed, uint64_t offset,
+                                const float* out_w, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
                                 float* d_query, void* d_kbag, void* d_tk_scratch, void* d_hbag,
@@ -295,7 +296,7 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
     // map side
     if ((rc = mpo_launch_bag_rowdot(hbag, f32, cu_rows, n_slides, E, dctx, ds1_map, 1.0f, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_gated_softmax_bwd(a_map, g_map, cu_rows, lse2, dasum, d_attn_map, ds1_map, dg_map, n_slides, n_q,
-                                           drop_p, seed, offset, stream))) return rc;
+                                           drop_p, seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), stream))) return rc;
     // query side: dq~ = ds1 K, dtq = dg TK
     if ((rc = mpo_launch_bag_colacc(kbag, kf32, cu_rows, n_slides, E, ds1_map, part, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part, dqt, n_slides, n_q, E, splits, stream))) return rc;
@@ -331,8 +332,9 @@ int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_row
 
 // ------------------------------------------------------------------------------------------- patch layer epilogue
 int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, int cols, float drop_p, uint64_t seed,
-                               uint64_t offset, mpo_stream_t stream) {
-    return mpo_launch_bias_relu_dropout_bf16(h_bf16, bias, (size_t)rows, cols, drop_p, seed, offset, stream);
+                               uint64_t offset, const uint64_t* rng_epoch, mpo_stream_t stream) {
+    return mpo_launch_bias_relu_dropout_bf16(h_bf16, bias, (size_t)rows, cols, drop_p, seed, offset,
+                                             reinterpret_cast<const unsigned long long*>(rng_epoch), stream);
 }
 int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, float drop_p,
                                 mpo_stream_t stream) {
@@ -341,9 +343,11 @@ int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g
 
 // ------------------------------------------------------------------------------------------- optimiser
 int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                       float beta1, float beta2, float eps, float weight_decay, int step, mpo_stream_t stream) {
-    MPO_CHECK(step >= 1, "adam: step counts from 1 (got %d)", step);
-    return mpo_launch_adam_flat(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, stream);
+                       float beta1, float beta2, float eps, float weight_decay, int step, const int32_t* step_dev,
+                       mpo_stream_t stream) {
+    MPO_CHECK(step >= 1 || step_dev, "adam: step counts from 1 (got %d)", step);
+    return mpo_launch_adam_flat(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay,
+                                step < 1 ? 1 : step, step_dev, stream);
 }
 
 }  // extern "C"

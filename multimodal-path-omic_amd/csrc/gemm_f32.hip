@@ -148,7 +148,8 @@ void gemm_f32_kernel(GemmArgs g) {
     const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
 
     GateFn gf;
-    gf.g = g.gate; gf.mode = g.gate_mode; gf.p = g.gate_p; gf.seed = g.gate_seed; gf.off = g.gate_off;
+    gf.g = g.gate; gf.mode = g.gate_mode; gf.p = g.gate_p; gf.seed = g.gate_seed;
+    gf.off = epoch_offset(g.gate_off, g.rng_epoch);
     gf.inv_keep = g.gate_p > 0.f ? 1.0f / (1.0f - g.gate_p) : 1.0f;
     const bool gated = g.gate_mode != MPO_GATE_NONE;
 
@@ -194,7 +195,8 @@ void gemm_f32_kernel(GemmArgs g) {
             float v = (acc0[r] + acc1[r] + bias) * g.alpha;
             v = apply_act(v, g.act);
             const size_t o = (size_t)m * g.ldc + n;
-            if (g.drop_p > 0.f) v *= dropout_keep(g.drop_seed, g.drop_off, o, g.drop_p, 1.0f / (1.0f - g.drop_p));
+            if (g.drop_p > 0.f)
+                v *= dropout_keep(g.drop_seed, epoch_offset(g.drop_off, g.rng_epoch), o, g.drop_p, 1.0f / (1.0f - g.drop_p));
             if (g.mask) v *= g.mask[o];
             if (g.residual) v += g.residual[o];
             if (g.accumulate) v += g.C[o];

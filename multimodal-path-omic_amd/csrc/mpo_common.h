@@ -58,6 +58,14 @@ __device__ __forceinline__ float dropout_keep(uint64_t seed, uint64_t offset, ui
     return u >= p ? inv_keep : 0.0f;
 }
 
+// Dropout streams are (seed, offset) by value plus an optional DEVICE-resident epoch: under HIP-graph replay
+// the by-value part is frozen, so the host bumps *epoch (a captured device op) once per step and every
+// stream moves by kEpochStride counters.  epoch == nullptr (eager mode) leaves the offset as passed.
+static constexpr unsigned long long kEpochStride = 1ull << 40;
+__device__ __forceinline__ unsigned long long epoch_offset(unsigned long long offset, const unsigned long long* epoch) {
+    return epoch ? offset + (*epoch) * kEpochStride : offset;
+}
+
 // ---- host-side error plumbing (one definition in capi.hip) ----
 void mpo_set_error(const char* fmt, ...);
 #define MPO_CHECK(cond, ...) do { if (!(cond)) { mpo_set_error(__VA_ARGS__); return 1; } } while (0)

@@ -40,17 +40,21 @@ struct GemmArgs {
     uint64_t gate_seed = 0, gate_off = 0;
     // dW GEMMs: bias_grad[m] = sum_k A(m,k) (after the gate) -- the bias gradient, for free
     float* bias_grad = nullptr;
+    // optional device-resident epoch added (x 2^40) to both dropout offsets (graph replay; mpo_common.h)
+    const unsigned long long* rng_epoch = nullptr;
 };
 
 struct DropSpec {                      // one dropout stream: p = 0 means "no dropout"
     float p = 0.f;
     uint64_t seed = 0, off = 0;
+    const unsigned long long* epoch = nullptr;
 };
 struct GateSpec {
     const float* g = nullptr;
     int mode = MPO_GATE_NONE;
     float p = 0.f;
     uint64_t seed = 0, off = 0;
+    const unsigned long long* epoch = nullptr;
 };
 
 int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream);
@@ -63,7 +67,7 @@ inline int mpo_linear_fwd(const float* x, const float* w, const float* b, float*
     GemmArgs g;
     g.A = x; g.B = w; g.C = y; g.bias = b; g.residual = residual;
     g.M = R; g.N = O; g.K = I; g.lda = I; g.ldb = I; g.ldc = O; g.alpha = alpha; g.act = act;
-    g.drop_p = drop.p; g.drop_seed = drop.seed; g.drop_off = drop.off;
+    g.drop_p = drop.p; g.drop_seed = drop.seed; g.drop_off = drop.off; g.rng_epoch = drop.epoch;
     return mpo_launch_gemm(g, 1, 1, s);
 }
 // dx[R][I] (+)= alpha * (dy*gate)[R][O] W[O][I]
@@ -73,6 +77,7 @@ inline int mpo_linear_bwd_input(const float* dy, const float* w, float* dx, int 
     g.A = dy; g.B = w; g.C = dx;
     g.M = R; g.N = I; g.K = O; g.lda = O; g.ldb = I; g.ldc = I; g.alpha = alpha; g.accumulate = accumulate;
     g.gate = gate.g; g.gate_mode = gate.mode; g.gate_p = gate.p; g.gate_seed = gate.seed; g.gate_off = gate.off;
+    g.rng_epoch = gate.epoch;
     return mpo_launch_gemm(g, 1, 0, s);
 }
 // dW[O][I] = alpha * (dy*gate)[R][O]^T x[R][I],   db[O] = column sums of dy*gate (nullable)
@@ -82,6 +87,7 @@ inline int mpo_linear_bwd_weight(const float* dy, const float* x, float* dw, flo
     g.A = dy; g.B = x; g.C = dw;
     g.M = O; g.N = I; g.K = R; g.lda = O; g.ldb = I; g.ldc = I; g.alpha = alpha;
     g.gate = gate.g; g.gate_mode = gate.mode; g.gate_p = gate.p; g.gate_seed = gate.seed; g.gate_off = gate.off;
+    g.rng_epoch = gate.epoch;
     g.bias_grad = db;
     return mpo_launch_gemm(g, 0, 0, s);
 }
@@ -114,11 +120,11 @@ int mpo_launch_bag_outer(const int* cu, int n_slides, int embed, const float* w1
                          const float* z2, void* dx, int out_f32, int n_q, int splits, hipStream_t stream);
 int mpo_launch_gated_softmax_fwd(const float* amap_a, const float* gmap, const int* cu, float* out_map, float* lse2,
                                  float* asum, int n_slides, int n_q, float drop_p, unsigned long long seed,
-                                 unsigned long long offset, hipStream_t stream);
+                                 unsigned long long offset, const unsigned long long* epoch, hipStream_t stream);
 int mpo_launch_gated_softmax_bwd(const float* amap_a, const float* gmap, const int* cu, const float* lse2,
                                  const float* dasum, const float* d_ext, float* da_map, float* dg_map, int n_slides,
                                  int n_q, float drop_p, unsigned long long seed, unsigned long long offset,
-                                 hipStream_t stream);
+                                 const unsigned long long* epoch, hipStream_t stream);
 int mpo_launch_bag_tanh_fwd(const void* x, void* y, size_t n, int f32, hipStream_t stream);
 int mpo_launch_bag_tanh_bwd(const void* y, const void* dy, void* dx, size_t n, int f32, hipStream_t stream);
 int mpo_launch_qprep(const float* q, float* qt, float* qs2, float* tq, int n, float c_nat, hipStream_t stream);
@@ -134,7 +140,8 @@ int mpo_launch_ln_bwd(const float* dy, const float* x, const float* stats, const
 int mpo_launch_ln_bwd_params_only(const float* dy, const float* x, const float* stats, float* dw, float* db, int rows, int d,
                                   hipStream_t s);
 int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, int T, int d, int H, float drop_p,
-                             unsigned long long seed, unsigned long long offset, hipStream_t s);
+                             unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
+                             hipStream_t s);
 int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float* d_o, float* dqkv, int B, int T, int d, int H,
                              hipStream_t s);
 int mpo_launch_pool_fwd(const float* scores, const float* x, float* w, float* h, int B, int L, int d, hipStream_t s);
@@ -154,9 +161,10 @@ int mpo_launch_cag_mid_bwd(const float* dm, const float* t1, const float* t3, co
 
 // h = drop(relu(h + bias)) in place on a bf16 [rows][cols] tensor (the patch layer's epilogue)
 int mpo_launch_bias_relu_dropout_bf16(void* h, const float* bias, size_t rows, int cols, float drop_p,
-                                      unsigned long long seed, unsigned long long offset, hipStream_t stream);
+                                      unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
+                                      hipStream_t stream);
 // g = dy * (h > 0 ? 1/(1-p) : 0) on bf16 tensors (derivative of the same epilogue)
 int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, size_t n, float drop_p, hipStream_t stream);
 
 int mpo_launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                         float wd, int step, hipStream_t stream);
+                         float wd, int step, const int* step_dev, hipStream_t stream);

@@ -81,8 +81,10 @@ constexpr int kMaxT = 16;
 
 __global__ __launch_bounds__(256)
 void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ p_save /* [B][H][T][T] x2: p, p_post */,
-                          int T, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset) {
+                          int T, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset_,
+                          const unsigned long long* epoch) {
     extern __shared__ float sm[];
+    const unsigned long long offset = epoch_offset(offset_, epoch);
     float* sq = sm;                       // [T][3d]
     float* sp = sm + T * 3 * d;           // [H][T][T]
     const int b = blockIdx.x, hd = d / H, tid = threadIdx.x;
@@ -384,10 +386,11 @@ int mpo_launch_ln_bwd_params_only(const float* dy, const float* x, const float* 
     return 0;
 }
 int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, int T, int d, int H, float drop_p,
-                             unsigned long long seed, unsigned long long offset, hipStream_t s) {
+                             unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
+                             hipStream_t s) {
     MPO_CHECK(T >= 1 && T <= kMaxT && d % H == 0, "set-transformer attention: T=%d (max %d), d=%d, heads=%d", T, kMaxT, d, H);
     const size_t lds = ((size_t)T * 3 * d + (size_t)H * T * T) * sizeof(float);
-    mha_small_fwd_kernel<<<B, 256, lds, s>>>(qkv, o, p_save, T, d, H, drop_p, seed, offset);
+    mha_small_fwd_kernel<<<B, 256, lds, s>>>(qkv, o, p_save, T, d, H, drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }

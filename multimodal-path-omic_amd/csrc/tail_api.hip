@@ -37,9 +37,10 @@ struct CarveSizer {
     float* take(size_t k) { n += (k + 63) / 64 * 64; return nullptr; }
 };
 
-inline DropSpec stream_of(float p, uint64_t seed, uint64_t base, uint64_t stride, int k) {
+inline DropSpec stream_of(float p, uint64_t seed, uint64_t base, uint64_t stride, int k, const uint64_t* epoch) {
     DropSpec d;
     d.p = p; d.seed = seed; d.off = base + stride * (uint64_t)k;
+    d.epoch = reinterpret_cast<const unsigned long long*>(epoch);
     return d;
 }
 inline GateSpec gate(const float* g, int mode, float p = 0.f) {
@@ -49,7 +50,7 @@ inline GateSpec gate(const float* g, int mode, float p = 0.f) {
 }
 inline GateSpec gate_rng(DropSpec d) {
     GateSpec s;
-    s.mode = d.p > 0.f ? MPO_GATE_RNG : MPO_GATE_NONE; s.p = d.p; s.seed = d.seed; s.off = d.off;
+    s.mode = d.p > 0.f ? MPO_GATE_RNG : MPO_GATE_NONE; s.p = d.p; s.seed = d.seed; s.off = d.off; s.epoch = d.epoch;
     return s;
 }
 
@@ -98,7 +99,7 @@ uint64_t mpo_encoder_rng_span(int n_slides, int T, int d, int ff, int layers) {
 // nn.TransformerEncoder (post-norm layers, ReLU FFN, no final norm): models/mcat/mcat.py:51-53,101-102;
 // layer arithmetic torch/nn/modules/transformer.py:661 (norm_first=False).
 int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
-                        const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                        const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                         float* y, float* saved, mpo_stream_t stream) {
     MPO_CHECK(n_slides >= 1 && layers >= 1 && d % heads == 0, "encoder: bad geometry (slides %d, layers %d, d %d, heads %d)",
               n_slides, layers, d, heads);
@@ -111,10 +112,10 @@ int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int 
         EncLayerSaved S;
         enc_carve(c, &S, n_slides, T, d, ff, heads);
         const uint64_t base = offset + stride * 4 * (uint64_t)l;
-        const DropSpec d0 = stream_of(drop_p, seed, base, stride, 0), d1 = stream_of(drop_p, seed, base, stride, 1),
-                       d2 = stream_of(drop_p, seed, base, stride, 2), d3 = stream_of(drop_p, seed, base, stride, 3);
+        const DropSpec d0 = stream_of(drop_p, seed, base, stride, 0, rng_epoch), d1 = stream_of(drop_p, seed, base, stride, 1, rng_epoch),
+                       d2 = stream_of(drop_p, seed, base, stride, 2, rng_epoch), d3 = stream_of(drop_p, seed, base, stride, 3, rng_epoch);
         RC(mpo_linear_fwd(in, P[P_INW], P[P_INB], S.qkv, R, d, 3 * d, 1.0f, MPO_ACT_NONE, stream));
-        RC(mpo_launch_mha_small_fwd(S.qkv, S.o, S.psave, n_slides, T, d, heads, d0.p, d0.seed, d0.off, stream));
+        RC(mpo_launch_mha_small_fwd(S.qkv, S.o, S.psave, n_slides, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, stream));
         RC(mpo_linear_fwd(S.o, P[P_OUTW], P[P_OUTB], S.s1, R, d, d, 1.0f, MPO_ACT_NONE, stream, in, d1));
         RC(mpo_launch_ln_fwd(S.s1, P[P_N1W], P[P_N1B], S.x1, S.st1, R, d, 1e-5f, stream));
         RC(mpo_linear_fwd(S.x1, P[P_L1W], P[P_L1B], S.f, R, d, ff, 1.0f, MPO_ACT_RELU, stream, nullptr, d2));
@@ -127,7 +128,7 @@ int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int 
 }
 
 int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
-                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                          const float* saved, const float* dy, float* dx, float* const* grads,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     const int R = n_slides * T;
@@ -149,7 +150,7 @@ int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int
         float* const* G = grads + l * P_PER_LAYER;
         const float* in = l == 0 ? x : S[l - 1].x2;
         const uint64_t base = offset + stride * 4 * (uint64_t)l;
-        const DropSpec d1 = stream_of(drop_p, seed, base, stride, 1), d3 = stream_of(drop_p, seed, base, stride, 3);
+        const DropSpec d1 = stream_of(drop_p, seed, base, stride, 1, rng_epoch), d3 = stream_of(drop_p, seed, base, stride, 3, rng_epoch);
         // x2 = LN2(s2)
         RC(mpo_launch_ln_bwd(dcur, S[l].s2, S[l].st2, P[P_N2W], ga, G[P_N2W], G[P_N2B], R, d, 0, stream));     // ga = ds2
         // s2 = x1 + drop3(f W2^T + b2)
@@ -196,19 +197,19 @@ uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d) { return 3 * ((uint
 // AttentionNetGated (models/blocks.py:13-48) + the pooling idiom of models/mcat/mcat.py:105-109:
 // scores = W_c[drop(tanh(W_a x)) * drop(sigmoid(W_b x))] + b_c; h = drop(relu(W_rho (softmax_L(scores) x) + b_rho))
 int mpo_gated_pool_forward(const float* x, int n_slides, int L, int d, const float* const* P,
-                           float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset,
+                           float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                            float* scores, float* h, float* saved, mpo_stream_t stream) {
     const int R = n_slides * L;
     const uint64_t stride = (uint64_t)R * d / 4 + 2;
     Carver c(saved);
     float* a = c.take((size_t)R * d); float* b = c.take((size_t)R * d); float* ab = c.take((size_t)R * d);
     float* w = c.take(R); float* hpool = c.take((size_t)n_slides * d);
-    RC(mpo_linear_fwd(x, P[0], P[1], a, R, d, d, 1.0f, MPO_ACT_TANH, stream, nullptr, stream_of(head_drop_p, seed, offset, stride, 0)));
-    RC(mpo_linear_fwd(x, P[2], P[3], b, R, d, d, 1.0f, MPO_ACT_SIGMOID, stream, nullptr, stream_of(head_drop_p, seed, offset, stride, 1)));
+    RC(mpo_linear_fwd(x, P[0], P[1], a, R, d, d, 1.0f, MPO_ACT_TANH, stream, nullptr, stream_of(head_drop_p, seed, offset, stride, 0, rng_epoch)));
+    RC(mpo_linear_fwd(x, P[2], P[3], b, R, d, d, 1.0f, MPO_ACT_SIGMOID, stream, nullptr, stream_of(head_drop_p, seed, offset, stride, 1, rng_epoch)));
     RC(mpo_launch_ew_mul(a, b, ab, R * d, stream));
     RC(mpo_linear_fwd(ab, P[4], P[5], scores, R, d, 1, 1.0f, MPO_ACT_NONE, stream));
     RC(mpo_launch_pool_fwd(scores, x, w, hpool, n_slides, L, d, stream));
-    RC(mpo_linear_fwd(hpool, P[6], P[7], h, n_slides, d, d, 1.0f, MPO_ACT_RELU, stream, nullptr, stream_of(rho_drop_p, seed, offset, stride, 2)));
+    RC(mpo_linear_fwd(hpool, P[6], P[7], h, n_slides, d, d, 1.0f, MPO_ACT_RELU, stream, nullptr, stream_of(rho_drop_p, seed, offset, stride, 2, rng_epoch)));
     return 0;
 }
 

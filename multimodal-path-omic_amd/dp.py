@@ -78,15 +78,17 @@ class FlatAdam:
             off += p.numel()
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
-        self.t = 0
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)   # step count, device-resident
 
     def step(self):
+        """One update.  The step count is incremented and read on the device, so the call can sit inside a
+        captured HIP graph and still apply the right bias correction on every replay."""
         from . import _lib as L
-        self.t += 1
+        self.t_dev += 1
         b = self.bucket
         L.check(L.lib().mpo_adam_step_flat(L.ptr(self.flat_p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                            self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                                           self.t, L.stream_of(self.flat_p)), "mpo_adam_step_flat")
+                                           0, L.ptr(self.t_dev), L.stream_of(self.flat_p)), "mpo_adam_step_flat")
 
 
 def assign_slides(lengths: Sequence[int], world_size: int) -> "List[List[int]]":

@@ -12,7 +12,6 @@ format: accumulation stays fp32, the 6 x d tail stays fp32 -- SURVEY.md section 
 """
 from __future__ import annotations
 
-import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -79,36 +78,14 @@ class _FusionModelBase(nn.Module):
         return torch.stack([g(o.float()) for g, o in zip(self.G, omics)], dim=1)
 
     def _tail(self, h_coattn, g_bag):
-        # The omic branch (T_G + rho_G) does not depend on the co-attention: it runs on a side HIP stream next
-        # to the path branch -- both are chains of small launches that leave most of the 256 CUs idle.
-        # Autograd replays each branch's backward on the stream its forward ran on.
-        if os.environ.get("MPO_NO_SIDE_STREAM"):
-            omic = self.omic_transformer(g_bag)
-            a_omic, h_omic = ops.gated_pool(omic, self.omic_attention_head, self.omic_rho, self.training)
-            path = self.path_transformer(h_coattn)
-            a_path, h_path = ops.gated_pool(path, self.path_attention_head, self.path_rho, self.training)
-            hazards, survs, y = ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
-            return hazards, survs, y, a_path, a_omic
-        main = torch.cuda.current_stream(g_bag.device)
-        side = self._side_stream(g_bag.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            omic = self.omic_transformer(g_bag)
-            a_omic, h_omic = ops.gated_pool(omic, self.omic_attention_head, self.omic_rho, self.training)
+        # (Running the omic branch on a side HIP stream was measured in round 1: no gain, the step is
+        # launch-bound on the host; harness.GraphedWindowStep removes that bound instead.)
+        omic = self.omic_transformer(g_bag)
+        a_omic, h_omic = ops.gated_pool(omic, self.omic_attention_head, self.omic_rho, self.training)
         path = self.path_transformer(h_coattn)
         a_path, h_path = ops.gated_pool(path, self.path_attention_head, self.path_rho, self.training)
-        main.wait_stream(side)
-        for t in (a_omic, h_omic):
-            t.record_stream(main)
         hazards, survs, y = ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
         return hazards, survs, y, a_path, a_omic
-
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            object.__setattr__(self, "_side", st)
-        return st
 
     # ---- window API
     def forward_window(self, bags: BagBatch, omics: "List[torch.Tensor]", inference: bool = False):

@@ -78,6 +78,20 @@ def grad_out(p):
     return torch.empty_like(p)
 
 
+_rng_epoch_tensor = None
+
+
+def set_rng_epoch(t):
+    """Install (or clear with None) the device uint64 scalar the kernels add (x 2^40) to their dropout offsets;
+    harness.GraphedWindowStep bumps it inside the captured graph so replays draw fresh masks."""
+    global _rng_epoch_tensor
+    _rng_epoch_tensor = t
+
+
+def _epoch():
+    return L.ptr(_rng_epoch_tensor) if _rng_epoch_tensor is not None else None
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -203,7 +217,7 @@ class PatchFcFn(torch.autograd.Function):
         h = torch.mm(x, weight.to(torch.bfloat16).t())
         seed, off = _reserve(h.numel() // 8 + 2) if drop_p > 0 else (0, 0)
         L.check(lib.mpo_patch_epilogue_forward(L.ptr(h), L.ptr(bias), h.shape[0], h.shape[1], float(drop_p), seed, off,
-                                               L.stream_of(h)), "mpo_patch_epilogue_forward")
+                                               _epoch(), L.stream_of(h)), "mpo_patch_epilogue_forward")
         ctx.save_for_backward(x, h)
         ctx.param_refs = (weight, bias)
         ctx.drop_p, ctx.pre_gated = float(drop_p), bool(pre_gated_grad)
@@ -326,7 +340,7 @@ class EncoderFn(torch.autograd.Function):
         seed, off = _reserve(lib.mpo_encoder_rng_span(n_slides, T, d, ff, layers)) if drop_p > 0 else (0, 0)
         pa = L.ptr_array(params)
         L.check(lib.mpo_encoder_forward(L.ptr(x), n_slides, T, d, ff, heads, layers, pa, float(drop_p), seed, off,
-                                        L.ptr(y), L.ptr(saved), L.stream_of(x)), "mpo_encoder_forward")
+                                        _epoch(), L.ptr(y), L.ptr(saved), L.stream_of(x)), "mpo_encoder_forward")
         ctx.save_for_backward(x, saved, *params)
         ctx.param_refs = params
         ctx.geom, ctx.drop = geom, (float(drop_p), seed, off)
@@ -343,7 +357,7 @@ class EncoderFn(torch.autograd.Function):
         ws = _workspace(lib.mpo_encoder_workspace_bytes(n_slides, T, d, ff), x.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         L.check(lib.mpo_encoder_backward(L.ptr(x), n_slides, T, d, ff, heads, layers, pa, drop_p, seed, off,
-                                         L.ptr(saved), L.ptr(dy.contiguous()), L.ptr(dx), ga, L.ptr(ws), ws.numel(),
+                                         _epoch(), L.ptr(saved), L.ptr(dy.contiguous()), L.ptr(dx), ga, L.ptr(ws), ws.numel(),
                                          L.stream_of(x)), "mpo_encoder_backward")
         return (dx, None, None, *grads)
 
@@ -376,7 +390,7 @@ class GatedPoolFn(torch.autograd.Function):
         seed, off = _reserve(lib.mpo_gated_pool_rng_span(n_slides, Lr, d)) if (head_p > 0 or rho_p > 0) else (0, 0)
         pa = L.ptr_array(params)
         L.check(lib.mpo_gated_pool_forward(L.ptr(x), n_slides, Lr, d, pa, float(head_p), float(rho_p), seed, off,
-                                           L.ptr(scores), L.ptr(h), L.ptr(saved), L.stream_of(x)),
+                                           _epoch(), L.ptr(scores), L.ptr(h), L.ptr(saved), L.stream_of(x)),
                 "mpo_gated_pool_forward")
         ctx.save_for_backward(x, saved, h, *params)
         ctx.param_refs = params
@@ -498,7 +512,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         L.check(lib.mpo_coattn_nacagat_forward(
             L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, T, batch.max_rows,
             L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), L.ptr(out_b), float(drop_p), seed, offset,
-            L.ptr(tkbag), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
+            _epoch(), L.ptr(tkbag), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
             L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_forward")
         ctx.save_for_backward(query, bag_data, kbag, tkbag, in_w, in_b, out_w, saved, score_maps, amap)
         ctx.param_refs = (in_w, in_b, out_w, out_b)
@@ -525,7 +539,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         L.check(lib.mpo_coattn_nacagat_backward(
             L.ptr(kbag), L.ptr(tkbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
-            L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
+            _epoch(), L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
             L.ptr(d_query), L.ptr(d_k), L.ptr(d_tk), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
             L.ptr(d_out_b), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
         # back through the caller-side GEMM  K = H W_k^T + b_k
