@@ -12,6 +12,7 @@ format: accumulation stays fp32, the 6 x d tail stays fp32 -- SURVEY.md section 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -77,25 +78,52 @@ class _FusionModelBase(nn.Module):
         """omics: per group a (B, d_i) tensor -> G_bag (B, N, d)."""
         return torch.stack([g(o.float()) for g, o in zip(self.G, omics)], dim=1)
 
-    def _tail(self, h_coattn, g_bag):
-        # (Running the omic branch on a side HIP stream was measured in round 1: no gain, the step is
-        # launch-bound on the host; harness.GraphedWindowStep removes that bound instead.)
+    def _omic_branch(self, g_bag):
         omic = self.omic_transformer(g_bag)
-        a_omic, h_omic = ops.gated_pool(omic, self.omic_attention_head, self.omic_rho, self.training)
+        return ops.gated_pool(omic, self.omic_attention_head, self.omic_rho, self.training)
+
+    def _path_branch(self, h_coattn):
         path = self.path_transformer(h_coattn)
-        a_path, h_path = ops.gated_pool(path, self.path_attention_head, self.path_rho, self.training)
-        hazards, survs, y = ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
-        return hazards, survs, y, a_path, a_omic
+        return ops.gated_pool(path, self.path_attention_head, self.path_rho, self.training)
 
     # ---- window API
     def forward_window(self, bags: BagBatch, omics: "List[torch.Tensor]", inference: bool = False):
         """bags: raw patch features (total_rows, 1024) of the window; omics: per group (B, d_i).
-        Returns hazards, survs, Y (B, C) and {'coattn': [ (N, M_b) ] | None, 'path': (B,1,N), 'omic': (B,1,N)}."""
-        h_bags = self._patch_fc(bags)
+        Returns hazards, survs, Y (B, C) and {'coattn': [ (N, M_b) ] | None, 'path': (B,1,N), 'omic': (B,1,N)}.
+
+        The omic branch (T_G + rho_G, models/mcat/mcat.py:102,111-115) depends only on G_bag, so it is forked
+        onto a side HIP stream and runs next to the patch layer and the co-attention, which are HBM-bound and
+        leave the matrix/vector pipes idle; autograd replays its backward on the same stream.  Eagerly the
+        step is host-bound and this buys nothing; inside a captured graph (harness.GraphedWindowStep) the two
+        chains really overlap."""
         g_bag = self._omic_fc(omics)
+        fork = self.fork_omic_branch and g_bag.is_cuda
+        if fork:
+            main = torch.cuda.current_stream(g_bag.device)
+            side = self._side_stream(g_bag.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                a_omic, h_omic = self._omic_branch(g_bag)
+        h_bags = self._patch_fc(bags)
         h_coattn, a_coattn = self._co_attend(g_bag, h_bags, inference)
-        hazards, survs, y, a_path, a_omic = self._tail(h_coattn, g_bag)
+        a_path, h_path = self._path_branch(h_coattn)
+        if fork:
+            main.wait_stream(side)
+            for t in (a_omic, h_omic):
+                t.record_stream(main)
+        else:
+            a_omic, h_omic = self._omic_branch(g_bag)
+        hazards, survs, y = ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
         return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
+
+    fork_omic_branch = not bool(os.environ.get("MPO_NO_FORK"))
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_side", st)
+        return st
 
     def _forward_one(self, wsi, omics, inference):
         """The reference's call: wsi (1,M,1024) or (M,1024); omics list of (1,d_i) or (d_i,)."""
