@@ -191,6 +191,20 @@ int mpo_cag_backward(const float* q, const float* q_hat, int rows, int dim, int 
                      const float* saved, const float* c_out, const float* d_c, float* d_q, float* d_q_hat,
                      float* const* grads, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
+/* ---- omic SNNs self.G (models/mcat/mcat.py:32-45,90-92): per group Linear+ELU+AlphaDropout twice, all groups
+ * per launch (grouped GEMM).  x[i] [n_slides, widths[i]] -> g_bag [n_slides, n_groups, d].  x, widths, params, grads are
+ * HOST arrays (of device pointers / ints).  4 pointers per group: 0.0.weight, 0.0.bias, 1.0.weight, 1.0.bias. */
+size_t mpo_omic_snn_saved_floats(int n_slides, int n_groups, int d);
+size_t mpo_omic_snn_workspace_bytes(int n_slides, int n_groups, int d);
+uint64_t mpo_omic_snn_rng_span(int n_slides, int n_groups, int d);
+int mpo_omic_snn_forward(const float* const* x, const int* widths, int n_groups, int n_slides, int d,
+                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                         const uint64_t* rng_epoch, float* g_bag, float* saved, mpo_stream_t stream);
+int mpo_omic_snn_backward(const float* const* x, const int* widths, int n_groups, int n_slides, int d,
+                          const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                          const uint64_t* rng_epoch, const float* g_bag, const float* saved, const float* d_g_bag,
+                          float* const* grads, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
 /* ---- the two bag-pass kernels of K1 on their own (bench.py times them with HIP events for the
  * roofline line; tests use them for kernel-level checks).  qk2 = log2(e) * (q/sqrt(E)) W_k, [n_slides*n_q, embed].
  * part_ml [n_slides*splits*32], part_ctx [n_slides*splits*n_q*embed] with splits = mpo_coattn_splits(). */

@@ -57,6 +57,12 @@ struct GateFn {
                 return sg * (1.0f - sg) * inv_keep;
             }
             case MPO_GATE_RNG: return dropout_keep(seed, off, idx, p, inv_keep);
+            case MPO_GATE_ELU_ADROP: {
+                if (p <= 0.f) return gv > 0.f ? 1.0f : gv + 1.0f;
+                if (dropout_keep(seed, off, idx, p, 1.0f) == 0.f) return 0.f;
+                const float a = alpha_drop_a(p), u = (gv - alpha_drop_b(p)) / a;
+                return a * (u > 0.f ? 1.0f : u + 1.0f);
+            }
             case MPO_GATE_MUL: return gv;
             default: return 1.0f;
         }
@@ -136,8 +142,23 @@ struct OperandStage {
 };
 
 template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g);
+
+template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256)
 void gemm_f32_kernel(GemmArgs g) {
+    gemm_f32_body<A_KC, B_KC>(g);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256)
+void gemm_f32_group_kernel(GemmGroup grp) {
+    gemm_f32_body<A_KC, B_KC>(grp.g[blockIdx.z]);
+}
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g) {
+    if ((int)blockIdx.y * BM >= g.M || (int)blockIdx.x * BN >= g.N) return;      // grouped launch: grid is the max extent
     __shared__ __attribute__((aligned(16))) float As[IMG_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[IMG_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -195,8 +216,15 @@ void gemm_f32_kernel(GemmArgs g) {
             float v = (acc0[r] + acc1[r] + bias) * g.alpha;
             v = apply_act(v, g.act);
             const size_t o = (size_t)m * g.ldc + n;
-            if (g.drop_p > 0.f)
-                v *= dropout_keep(g.drop_seed, epoch_offset(g.drop_off, g.rng_epoch), o, g.drop_p, 1.0f / (1.0f - g.drop_p));
+            if (g.drop_p > 0.f) {
+                const unsigned long long doff = epoch_offset(g.drop_off, g.rng_epoch);
+                if (g.alpha_dropout) {
+                    const bool keep = dropout_keep(g.drop_seed, doff, o, g.drop_p, 1.0f) != 0.f;
+                    v = alpha_drop_a(g.drop_p) * (keep ? v : kAlphaPrime) + alpha_drop_b(g.drop_p);
+                } else {
+                    v *= dropout_keep(g.drop_seed, doff, o, g.drop_p, 1.0f / (1.0f - g.drop_p));
+                }
+            }
             if (g.mask) v *= g.mask[o];
             if (g.residual) v += g.residual[o];
             if (g.accumulate) v += g.C[o];
@@ -232,6 +260,24 @@ int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream) {
     else if (a_kc && !b_kc) gemm_f32_kernel<true, false><<<grid, 256, 0, stream>>>(g);
     else if (!a_kc && b_kc) gemm_f32_kernel<false, true><<<grid, 256, 0, stream>>>(g);
     else gemm_f32_kernel<false, false><<<grid, 256, 0, stream>>>(g);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_gemm_group(const GemmGroup& grp, int a_kc, int b_kc, hipStream_t stream) {
+    MPO_CHECK(grp.n >= 1 && grp.n <= 8, "grouped gemm: 1..8 members (got %d)", grp.n);
+    int mx = 0, nx = 0;
+    for (int i = 0; i < grp.n; ++i) {
+        MPO_CHECK(grp.g[i].K > 0, "grouped gemm: member %d has K = %d", i, grp.g[i].K);
+        if (grp.g[i].M > mx) mx = grp.g[i].M;
+        if (grp.g[i].N > nx) nx = grp.g[i].N;
+    }
+    if (mx <= 0 || nx <= 0) return 0;
+    dim3 grid((nx + BN - 1) / BN, (mx + BM - 1) / BM, grp.n);
+    if (a_kc && b_kc) gemm_f32_group_kernel<true, true><<<grid, 256, 0, stream>>>(grp);
+    else if (a_kc && !b_kc) gemm_f32_group_kernel<true, false><<<grid, 256, 0, stream>>>(grp);
+    else if (!a_kc && b_kc) gemm_f32_group_kernel<false, true><<<grid, 256, 0, stream>>>(grp);
+    else gemm_f32_group_kernel<false, false><<<grid, 256, 0, stream>>>(grp);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -58,6 +58,11 @@ __device__ __forceinline__ float dropout_keep(uint64_t seed, uint64_t offset, ui
     return u >= p ? inv_keep : 0.0f;
 }
 
+// nn.AlphaDropout(p) constants: y = a * (keep ? x : alpha') + b  (self-normalising dropout of the omic SNNs)
+static constexpr float kAlphaPrime = -1.7580993408473766f;
+__host__ __device__ __forceinline__ float alpha_drop_a(float p) { return 1.0f / sqrtf((1.0f - p) * (1.0f + p * kAlphaPrime * kAlphaPrime)); }
+__host__ __device__ __forceinline__ float alpha_drop_b(float p) { return -alpha_drop_a(p) * kAlphaPrime * p; }
+
 // Dropout streams are (seed, offset) by value plus an optional DEVICE-resident epoch: under HIP-graph replay
 // the by-value part is frozen, so the host bumps *epoch (a captured device op) once per step and every
 // stream moves by kEpochStride counters.  epoch == nullptr (eager mode) leaves the offset as passed.

@@ -15,8 +15,9 @@ enum { MPO_ACT_NONE = 0, MPO_ACT_RELU = 1, MPO_ACT_ELU = 2, MPO_ACT_TANH = 3, MP
 //   SIGMOID G = drop(sigmoid(pre)): s = G(1-p);  G != 0 ? s(1-s)/(1-p) : 0
 //   RNG     no tensor: the keep-scale of the dropout stream (gate_seed, gate_off) at the element's index
 //   MUL     plain element-wise factor G
+//   ELU_ADROP G = alpha_dropout_p(elu(pre)) (nn.AlphaDropout): keep = stream bit; u = (G - b)/a; keep ? a * elu'(u) : 0
 enum { MPO_GATE_NONE = 0, MPO_GATE_RELU = 1, MPO_GATE_ELU = 2, MPO_GATE_TANH = 3, MPO_GATE_SIGMOID = 4,
-       MPO_GATE_RNG = 5, MPO_GATE_MUL = 6 };
+       MPO_GATE_RNG = 5, MPO_GATE_MUL = 6, MPO_GATE_ELU_ADROP = 7 };
 
 struct GemmArgs {
     const float* A = nullptr;
@@ -30,7 +31,9 @@ struct GemmArgs {
     float alpha = 1.0f;
     int act = MPO_ACT_NONE;
     int accumulate = 0;                // C += result
-    // epilogue dropout (after the activation): C *= keep-scale of stream (drop_seed, drop_off) at index m*ldc+n
+    // epilogue dropout (after the activation): C *= keep-scale of stream (drop_seed, drop_off) at index m*ldc+n;
+    // alpha_dropout != 0 selects nn.AlphaDropout's form instead: C = a * (keep ? C : alpha') + b
+    int alpha_dropout = 0;
     float drop_p = 0.f;
     uint64_t drop_seed = 0, drop_off = 0;
     // A-operand gate (see MPO_GATE_*)
@@ -58,6 +61,12 @@ struct GateSpec {
 };
 
 int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream);
+// up to 8 independent GEMMs of the same operand layout in ONE launch (blockIdx.z picks the member)
+struct GemmGroup {
+    GemmArgs g[8];
+    int n = 0;
+};
+int mpo_launch_gemm_group(const GemmGroup& grp, int a_kc, int b_kc, hipStream_t stream);
 int mpo_launch_colsum(const float* x, float* out, int M, int N, int ld, int accumulate, hipStream_t stream);
 
 // y[R][O] = drop(act(alpha * (x[R][I] W[O][I]^T + b))) [+ residual]

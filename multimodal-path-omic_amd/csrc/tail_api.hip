@@ -356,4 +356,88 @@ int mpo_cag_backward(const float* q, const float* q_hat, int rows, int dim, int 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- omic SNNs (self.G)
+// models/mcat/mcat.py:32-45,90-92: per omic group i  G_i(x) = AD(ELU(W2 AD(ELU(W1 x + b1)) + b2)), AD = AlphaDropout(p).
+// All groups advance together: ONE grouped GEMM launch per layer (blockIdx.z = group).  x_i [n_slides, width_i];
+// the second layer writes straight into G_bag [n_slides, n_groups, d] (row stride n_groups * d).
+// params per group: 0.0.weight [d, width_i], 0.0.bias, 1.0.weight [d, d], 1.0.bias        saved: u1 [n_groups][n_slides, d]
+size_t mpo_omic_snn_saved_floats(int n_slides, int n_groups, int d) {
+    CarveSizer c;
+    for (int i = 0; i < n_groups; ++i) c.take((size_t)n_slides * d);
+    return c.n;
+}
+size_t mpo_omic_snn_workspace_bytes(int n_slides, int n_groups, int d) {
+    Sizer s;
+    for (int i = 0; i < n_groups; ++i) s.floats((size_t)n_slides * d);
+    return s.off + 256;
+}
+uint64_t mpo_omic_snn_rng_span(int n_slides, int n_groups, int d) { return 2ull * n_groups * ((uint64_t)n_slides * n_groups * d / 4 + 2); }
+
+int mpo_omic_snn_forward(const float* const* x, const int* widths, int n_groups, int n_slides, int d,
+                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                         const uint64_t* rng_epoch, float* g_bag, float* saved, mpo_stream_t stream) {
+    MPO_CHECK(n_groups >= 1 && n_groups <= 8, "omic SNN: 1..8 groups per call (got %d)", n_groups);
+    const uint64_t stride = (uint64_t)n_slides * n_groups * d / 4 + 2;
+    Carver c(saved);
+    GemmGroup l1, l2;
+    l1.n = l2.n = n_groups;
+    for (int i = 0; i < n_groups; ++i) {
+        float* u1 = c.take((size_t)n_slides * d);
+        const float* const* P = params + 4 * i;
+        GemmArgs& a = l1.g[i];
+        a.A = x[i]; a.B = P[0]; a.bias = P[1]; a.C = u1;
+        a.M = n_slides; a.N = d; a.K = widths[i]; a.lda = widths[i]; a.ldb = widths[i]; a.ldc = d;
+        a.act = MPO_ACT_ELU; a.alpha_dropout = 1; a.drop_p = drop_p; a.drop_seed = seed; a.drop_off = offset + stride * (2 * i);
+        a.rng_epoch = reinterpret_cast<const unsigned long long*>(rng_epoch);
+        GemmArgs& b = l2.g[i];
+        b.A = u1; b.B = P[2]; b.bias = P[3]; b.C = g_bag + (size_t)i * d;
+        b.M = n_slides; b.N = d; b.K = d; b.lda = d; b.ldb = d; b.ldc = n_groups * d;
+        b.act = MPO_ACT_ELU; b.alpha_dropout = 1; b.drop_p = drop_p; b.drop_seed = seed; b.drop_off = offset + stride * (2 * i + 1);
+        b.rng_epoch = a.rng_epoch;
+    }
+    RC(mpo_launch_gemm_group(l1, 1, 1, stream));
+    RC(mpo_launch_gemm_group(l2, 1, 1, stream));
+    return 0;
+}
+
+int mpo_omic_snn_backward(const float* const* x, const int* widths, int n_groups, int n_slides, int d,
+                          const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
+                          const uint64_t* rng_epoch, const float* g_bag, const float* saved, const float* d_g_bag,
+                          float* const* grads, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    MPO_CHECK(n_groups >= 1 && n_groups <= 8, "omic SNN: 1..8 groups per call (got %d)", n_groups);
+    const uint64_t stride = (uint64_t)n_slides * n_groups * d / 4 + 2;
+    Carver c(const_cast<float*>(saved));
+    Arena ws(workspace, workspace_bytes);
+    GemmGroup dx, dw2, dw1;
+    dx.n = dw2.n = dw1.n = n_groups;
+    const unsigned long long* ep = reinterpret_cast<const unsigned long long*>(rng_epoch);
+    for (int i = 0; i < n_groups; ++i) {
+        const float* u1 = c.take((size_t)n_slides * d);
+        float* du1 = ws.floats((size_t)n_slides * d);
+        MPO_CHECK(du1, "omic SNN backward: workspace too small (%zu bytes)", workspace_bytes);
+        const float* const* P = params + 4 * i;
+        float* const* G = grads + 4 * i;
+        const float* dy = d_g_bag + (size_t)i * d;          // [n_slides, d] with row stride n_groups * d
+        const float* y = g_bag + (size_t)i * d;
+        const int ldy = n_groups * d;
+        // layer 2: y = AD(ELU(u1 W2^T + b2)); gate indexed like y (row stride ldy) -> same stream index as forward
+        GemmArgs& a = dx.g[i];                               // du1 = (dy*gate) W2
+        a.A = dy; a.B = P[2]; a.C = du1; a.M = n_slides; a.N = d; a.K = d; a.lda = ldy; a.ldb = d; a.ldc = d;
+        a.gate = y; a.gate_mode = MPO_GATE_ELU_ADROP; a.gate_p = drop_p; a.gate_seed = seed; a.gate_off = offset + stride * (2 * i + 1);
+        a.rng_epoch = ep;
+        GemmArgs& b = dw2.g[i];                              // dW2 = (dy*gate)^T u1, db2
+        b.A = dy; b.B = u1; b.C = G[2]; b.bias_grad = G[3]; b.M = d; b.N = d; b.K = n_slides; b.lda = ldy; b.ldb = d; b.ldc = d;
+        b.gate = y; b.gate_mode = MPO_GATE_ELU_ADROP; b.gate_p = drop_p; b.gate_seed = seed; b.gate_off = a.gate_off; b.rng_epoch = ep;
+        GemmArgs& e = dw1.g[i];                              // dW1 = (du1*gate1)^T x, db1   (x needs no gradient: it is data)
+        e.A = du1; e.B = x[i]; e.C = G[0]; e.bias_grad = G[1]; e.M = d; e.N = widths[i]; e.K = n_slides; e.lda = d; e.ldb = widths[i];
+        e.ldc = widths[i];
+        e.gate = u1; e.gate_mode = MPO_GATE_ELU_ADROP; e.gate_p = drop_p; e.gate_seed = seed; e.gate_off = offset + stride * (2 * i);
+        e.rng_epoch = ep;
+    }
+    RC(mpo_launch_gemm_group(dx, 1, 0, stream));
+    RC(mpo_launch_gemm_group(dw2, 0, 0, stream));
+    RC(mpo_launch_gemm_group(dw1, 0, 0, stream));
+    return 0;
+}
+
 }  // extern "C"

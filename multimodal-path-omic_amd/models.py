@@ -76,7 +76,7 @@ class _FusionModelBase(nn.Module):
 
     def _omic_fc(self, omics: "List[torch.Tensor]") -> torch.Tensor:
         """omics: per group a (B, d_i) tensor -> G_bag (B, N, d)."""
-        return torch.stack([g(o.float()) for g, o in zip(self.G, omics)], dim=1)
+        return ops.omic_snn(omics, self.G, self.training)
 
     def _omic_branch(self, g_bag):
         omic = self.omic_transformer(g_bag)

@@ -6,6 +6,7 @@ tensors, workspaces) are torch allocations; the library keeps nothing.
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -427,6 +428,55 @@ def gated_pool(tokens, head, rho, training: bool):
     scores, h = GatedPoolFn.apply(tokens.reshape(b * l, d), (b, l, d), head.drop_p if training else 0.0,
                                   rho[2].p if training else 0.0, *params)
     return scores.view(b, 1, l), h
+
+
+class OmicSnnFn(torch.autograd.Function):
+    """self.G: all omic SNNs of a window in grouped launches (models/mcat/mcat.py:32-45,90-92)."""
+
+    @staticmethod
+    def forward(ctx, drop_p, n_groups, *args):
+        lib = L.lib()
+        xs, params = [a.contiguous() for a in args[:n_groups]], args[n_groups:]
+        n_slides, d = xs[0].shape[0], params[0].shape[0]
+        dev = xs[0].device
+        widths = (ctypes.c_int * n_groups)(*[int(x.shape[1]) for x in xs])
+        g_bag = torch.empty(n_slides, n_groups, d, device=dev, dtype=torch.float32)
+        saved = torch.empty(lib.mpo_omic_snn_saved_floats(n_slides, n_groups, d), device=dev, dtype=torch.float32)
+        seed, off = _reserve(lib.mpo_omic_snn_rng_span(n_slides, n_groups, d)) if drop_p > 0 else (0, 0)
+        xa, pa = L.ptr_array(xs), L.ptr_array(params)
+        L.check(lib.mpo_omic_snn_forward(xa, widths, n_groups, n_slides, d, pa, float(drop_p), seed, off, _epoch(),
+                                         L.ptr(g_bag), L.ptr(saved), L.stream_of(g_bag)), "mpo_omic_snn_forward")
+        ctx.save_for_backward(g_bag, saved, *xs, *params)
+        ctx.param_refs, ctx.n_groups, ctx.drop = params, n_groups, (float(drop_p), seed, off)
+        return g_bag
+
+    @staticmethod
+    def backward(ctx, d_g):
+        lib = L.lib()
+        g_bag, saved, *rest = ctx.saved_tensors
+        n = ctx.n_groups
+        xs, params = rest[:n], rest[n:]
+        n_slides, d = xs[0].shape[0], params[0].shape[0]
+        drop_p, seed, off = ctx.drop
+        widths = (ctypes.c_int * n)(*[int(x.shape[1]) for x in xs])
+        grads = [grad_out(p) for p in ctx.param_refs]
+        ws = _workspace(lib.mpo_omic_snn_workspace_bytes(n_slides, n, d), g_bag.device)
+        xa, pa, ga = L.ptr_array(xs), L.ptr_array(params), L.ptr_array(grads)
+        L.check(lib.mpo_omic_snn_backward(xa, widths, n, n_slides, d, pa, drop_p, seed, off, _epoch(), L.ptr(g_bag),
+                                          L.ptr(saved), L.ptr(d_g.contiguous()), ga, L.ptr(ws), ws.numel(),
+                                          L.stream_of(g_bag)), "mpo_omic_snn_backward")
+        return (None, None, *([None] * n), *grads)
+
+
+def omic_snn(omics, g_modules, training: bool):
+    """omics: per group (B, d_i) -> G_bag (B, N, d).  g_modules: the nn.ModuleList self.G (parameter holders)."""
+    if len(omics) > 8:
+        raise NotImplementedError("omic SNN kernel: at most 8 omic groups per call")
+    params = []
+    for g in g_modules:
+        params += [g[0][0].weight, g[0][0].bias, g[1][0].weight, g[1][0].bias]
+    p = g_modules[0][0][2].p if training else 0.0
+    return OmicSnnFn.apply(p, len(omics), *[o.float() for o in omics], *params)
 
 
 class FusionHeadFn(torch.autograd.Function):

@@ -140,3 +140,55 @@ def test_training_dropout_forward_backward_use_the_same_masks(dev, which):
     ops._rng_calls = 99999
     again = float((mod(x) * probe).sum()) if which == "encoder" else float(ops.gated_pool(x, head, rho, True)[1].sum())
     assert other == again and other != same
+
+
+def test_omic_snn_matches_stock_modules_and_alpha_dropout(dev):
+    """self.G (models/mcat/mcat.py:32-45): grouped-GEMM family == the stock nn.Sequential stack in eval mode
+    (values and gradients); in training mode AlphaDropout keeps ~(1-p) of the activations, replaces the rest by
+    the constant a*alpha'+b, and forward/backward use the same mask (finite differences, counter pinned)."""
+    import torch.nn as nn
+    sizes = [100, 31, 256, 8, 300, 64]
+    torch.manual_seed(3)
+    G = nn.ModuleList([nn.Sequential(
+        nn.Sequential(nn.Linear(s, C.E), nn.ELU(), nn.AlphaDropout(p=0.25, inplace=False)),
+        nn.Sequential(nn.Linear(C.E, C.E), nn.ELU(), nn.AlphaDropout(p=0.25, inplace=False))) for s in sizes]).to(dev)
+    g = syn.rng(41)
+    b = 5
+    xs = [syn.normal(g, (b, s)).to(dev) for s in sizes]
+    probe = syn.normal(g, (b, len(sizes), C.E)).to(dev)
+    G.eval()
+    ref = torch.stack([m(x) for m, x in zip(G, xs)], dim=1)
+    got = ops.omic_snn(xs, G, training=False)
+    assert relerr(got, ref) < 1e-5
+    gr_ref = torch.autograd.grad((ref * probe).sum(), list(G.parameters()))
+    gr_got = torch.autograd.grad((got * probe).sum(), list(G.parameters()))
+    for a, r in zip(gr_got, gr_ref):
+        assert float((a - r).abs().max()) / max(float(r.abs().max()), 1e-6) < 1e-4
+    # training mode
+    G.train()
+    ops._rng_calls = 777
+    y = ops.omic_snn(xs, G, training=True)
+    p = 0.25
+    a_c = 1.0 / ((1 - p) * (1 + p * 1.7580993408473766 ** 2)) ** 0.5
+    const = a_c * (-1.7580993408473766) + (a_c * 1.7580993408473766 * p)
+    frac = float(((y - const).abs() < 1e-6).float().mean())
+    assert abs(frac - p) < 0.03, frac
+    v = [syn.normal(g, tuple(q.shape)).to(dev) * 0.5 for q in G.parameters()]
+
+    def f(scale):
+        ops._rng_calls = 777
+        with torch.no_grad():
+            for q, d in zip(G.parameters(), v):
+                q.add_(scale * d)
+        out = float((ops.omic_snn(xs, G, True) * probe).sum().double())
+        with torch.no_grad():
+            for q, d in zip(G.parameters(), v):
+                q.sub_(scale * d)
+        return out
+    ops._rng_calls = 777
+    yy = ops.omic_snn(xs, G, True)
+    grads = torch.autograd.grad((yy * probe).sum(), list(G.parameters()))
+    ana = sum(float((gq * d).sum()) for gq, d in zip(grads, v))
+    eps = 1e-3
+    num = (f(eps) - f(-eps)) / (2 * eps)
+    assert abs(ana - num) < 3e-2 * max(1.0, abs(num)), (ana, num)
