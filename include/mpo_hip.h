@@ -36,6 +36,10 @@ enum { MPO_ACT_NONE_ = 0, MPO_ACT_RELU_ = 1, MPO_ACT_ELU_ = 2, MPO_ACT_TANH_ = 3
 
 int mpo_abi_version(void);
 const char* mpo_last_error(void);
+/* Once per process and device, outside any stream capture: creates the library's one helper stream and its
+ * events.  Backward entries fork their weight-gradient work onto it and join before returning (two parallel
+ * branches under HIP-graph capture).  enable_side_stream = 0 keeps everything on the caller's stream. */
+int mpo_prepare_device(int enable_side_stream);
 
 /* ---- building block: y = act(alpha * (x W^T + b)) and its two backward products, on the fp32 MFMA.
  * Stands in for torch.nn.functional.linear on the 6 x 256-token tail. */
@@ -88,6 +92,8 @@ int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, in
                                uint64_t offset, const uint64_t* rng_epoch, mpo_stream_t stream);
 int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, float drop_p,
                                 mpo_stream_t stream);
+/* out[c] = sum_r x[r][c] for a bf16 [rows, cols] tensor: the bias gradient of self.H (torch's reduce: 142 us) */
+int mpo_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, mpo_stream_t stream);
 
 /* ---- optimiser step of the reference's default `adam` (models/mcat/main.py:284-300: torch.optim.Adam(lr, weight_decay))
  * over ONE flat parameter / gradient / moment buffer: g' = g + wd p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;

@@ -36,6 +36,8 @@ _SIGNATURES = {
                                         _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    "mpo_prepare_device": (c_int, [c_int]),
+    "mpo_colsum_bf16": (c_int, [_P, _P, ctypes.c_int64, c_int, _P]),
     "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     "mpo_patch_epilogue_forward": (c_int, [_P, _P, ctypes.c_int64, c_int, c_float, c_uint64, c_uint64, _P, _P]),
     "mpo_patch_epilogue_backward": (c_int, [_P, _P, _P, ctypes.c_int64, c_float, _P]),
@@ -94,6 +96,19 @@ def lib():
     return _lib
 
 
+_prepared = set()
+
+
+def prepare_device(device):
+    """Create the library's helper stream for `device` (must happen outside graph capture; ops call this on
+    every entry, it is a set lookup after the first time)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _prepared:
+        with torch.cuda.device(idx):
+            check(lib().mpo_prepare_device(0 if os.environ.get("MPO_NO_SIDE_STREAM") else 1), "mpo_prepare_device")
+        _prepared.add(idx)
+
+
 def check(rc: int, what: str):
     if rc != 0:
         msg = lib().mpo_last_error()
@@ -120,6 +135,7 @@ def ptr_array(tensors):
 
 
 def stream_of(t):
+    prepare_device(t.device)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

@@ -411,6 +411,33 @@ __global__ void relu_dropout_bwd_bf16_kernel(const bf16x8* __restrict__ h, const
     }
 }
 
+// out[c] = sum_r x[r][c] over a bf16 [rows][cols] tensor (cols = 8 * a divisor of 256): the patch layer's bias gradient.
+// Each thread owns 8 fixed columns (16-byte loads), workgroups take row chunks, fp32 atomics merge them.
+__global__ __launch_bounds__(256)
+void colsum_bf16_kernel(const bf16x8* __restrict__ x, float* __restrict__ out, size_t rows, int cols) {
+    const int tpr = cols / 8;                       // threads per row
+    const int rpb = 256 / tpr;                      // rows per block-iteration
+    const int c8 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t r = (size_t)blockIdx.x * rpb + rl; r < rows; r += (size_t)gridDim.x * rpb) {
+        const bf16x8 v = x[r * tpr + c8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+    __shared__ float red[256][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = 0.f;
+            for (int k = 0; k < rpb; ++k) t += red[k * tpr + c8][j];
+            atomicAdd(out + 8 * c8 + j, t);
+        }
+    }
+}
+
 // torch.optim.Adam semantics (L2 weight decay folded into the gradient), one pass over the flat buffers
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
@@ -438,6 +465,17 @@ int mpo_launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n,
     const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     adam_flat_kernel<<<blocks, 256, 0, stream>>>(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, step_dev);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_colsum_bf16(const void* x, float* out, size_t rows, int cols, hipStream_t stream) {
+    MPO_CHECK(cols % 8 == 0 && 256 % (cols / 8) == 0, "bf16 column sum: width %d must be 8 * a divisor of 256", cols);
+    MPO_HIP(hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), stream));
+    const size_t rpb = 256 / (cols / 8);
+    size_t blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 2048) blocks = 2048;
+    colsum_bf16_kernel<<<(int)blocks, 256, 0, stream>>>((const bf16x8*)x, out, rows, cols);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -89,7 +89,9 @@ size_t mpo_encoder_saved_floats(int n_slides, int T, int d, int ff, int heads, i
 size_t mpo_encoder_workspace_bytes(int n_slides, int T, int d, int ff) {
     const size_t R = (size_t)n_slides * T;
     Sizer s;
-    s.floats(R * d); s.floats(R * d); s.floats(R * ff); s.floats(R * d); s.floats(R * 3 * d);
+    for (int l = 0; l < 8; ++l) {                          // one buffer set per layer (max 8 layers)
+        s.floats(R * d); s.floats(R * ff); s.floats(R * d); s.floats(R * d); s.floats(R * d); s.floats(R * 3 * d); s.floats(R * d);
+    }
     return s.off + 256;
 }
 uint64_t mpo_encoder_rng_span(int n_slides, int T, int d, int ff, int layers) {
@@ -133,47 +135,63 @@ int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     const int R = n_slides * T;
     const uint64_t stride = enc_stream_stride(n_slides, T, d, ff);
-    Arena ws(workspace, workspace_bytes);
-    float* ga = ws.floats((size_t)R * d);
-    float* gb = ws.floats((size_t)R * d);
-    float* df = ws.floats((size_t)R * ff);
-    float* dob = ws.floats((size_t)R * d);
-    float* dqkv = ws.floats((size_t)R * 3 * d);
-    MPO_CHECK(ga && gb && df && dob && dqkv, "encoder backward: workspace too small (%zu bytes)", workspace_bytes);
-    EncLayerSaved S[8];
     MPO_CHECK(layers <= 8, "encoder: at most 8 layers (got %d)", layers);
+    EncLayerSaved S[8];
     Carver c(const_cast<float*>(saved));
     for (int l = 0; l < layers; ++l) enc_carve(c, &S[l], n_slides, T, d, ff, heads);
+    Arena ws(workspace, workspace_bytes);
+    // The critical chain (LayerNorm / input-gradient GEMMs / attention) runs on the caller's stream; weight-gradient
+    // GEMMs and LayerNorm parameter reductions go to the side stream right after their inputs exist.  Nothing is
+    // updated in place and every layer has its own buffer set, so the side work only has to be joined at the end.
+    SideFork fork(stream);
     const float* dcur = dy;
     for (int l = layers - 1; l >= 0; --l) {
+        float* ds2 = ws.floats((size_t)R * d);
+        float* df = ws.floats((size_t)R * ff);
+        float* dx1 = ws.floats((size_t)R * d);
+        float* ds1 = ws.floats((size_t)R * d);
+        float* dob = ws.floats((size_t)R * d);
+        float* dqkv = ws.floats((size_t)R * 3 * d);
+        float* din = l == 0 ? dx : ws.floats((size_t)R * d);
+        MPO_CHECK(ds2 && df && dx1 && ds1 && dob && dqkv && din, "encoder backward: workspace too small (%zu bytes)", workspace_bytes);
         const float* const* P = params + l * P_PER_LAYER;
         float* const* G = grads + l * P_PER_LAYER;
         const float* in = l == 0 ? x : S[l - 1].x2;
         const uint64_t base = offset + stride * 4 * (uint64_t)l;
         const DropSpec d1 = stream_of(drop_p, seed, base, stride, 1, rng_epoch), d3 = stream_of(drop_p, seed, base, stride, 3, rng_epoch);
         // x2 = LN2(s2)
-        RC(mpo_launch_ln_bwd(dcur, S[l].s2, S[l].st2, P[P_N2W], ga, G[P_N2W], G[P_N2B], R, d, 0, stream));     // ga = ds2
+        RC(mpo_launch_ln_bwd(dcur, S[l].s2, S[l].st2, P[P_N2W], ds2, nullptr, nullptr, R, d, 0, stream));
+        RC(mpo_launch_ln_bwd_params_only(dcur, S[l].s2, S[l].st2, G[P_N2W], G[P_N2B], R, d, fork.sync()));
         // s2 = x1 + drop3(f W2^T + b2)
-        RC(mpo_linear_bwd_input(ga, P[P_L2W], df, R, ff, d, 1.0f, 0, stream, gate_rng(d3)));                     // df
-        RC(mpo_linear_bwd_weight(ga, S[l].f, G[P_L2W], G[P_L2B], R, ff, d, 1.0f, stream, gate_rng(d3)));
-        // f = drop2(relu(x1 W1^T + b1));  dx1 = ds2 + (df*gate) W1   (accumulated in place into ga)
-        RC(mpo_linear_bwd_input(df, P[P_L1W], ga, R, d, ff, 1.0f, 1, stream, gate(S[l].f, MPO_GATE_RELU, drop_p)));
-        RC(mpo_linear_bwd_weight(df, S[l].x1, G[P_L1W], G[P_L1B], R, d, ff, 1.0f, stream, gate(S[l].f, MPO_GATE_RELU, drop_p)));
-        // x1 = LN1(s1)
-        RC(mpo_launch_ln_bwd(ga, S[l].s1, S[l].st1, P[P_N1W], gb, G[P_N1W], G[P_N1B], R, d, 0, stream));        // gb = ds1
-        // s1 = in + drop1(o W_o^T + b_o)
-        RC(mpo_linear_bwd_input(gb, P[P_OUTW], dob, R, d, d, 1.0f, 0, stream, gate_rng(d1)));
-        RC(mpo_linear_bwd_weight(gb, S[l].o, G[P_OUTW], G[P_OUTB], R, d, d, 1.0f, stream, gate_rng(d1)));
-        RC(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, n_slides, T, d, heads, stream));
-        // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in  (accumulated in place into gb)
-        RC(mpo_linear_bwd_input(dqkv, P[P_INW], gb, R, d, 3 * d, 1.0f, 1, stream));
-        RC(mpo_linear_bwd_weight(dqkv, in, G[P_INW], G[P_INB], R, d, 3 * d, 1.0f, stream));
-        if (l == 0) {
-            MPO_HIP(hipMemcpyAsync(dx, gb, (size_t)R * d * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        } else {
-            dcur = gb;      // the layer below reads its upstream gradient from gb; its first LN-backward writes ga
+        RC(mpo_linear_bwd_input(ds2, P[P_L2W], df, R, ff, d, 1.0f, 0, stream, gate_rng(d3)));
+        RC(mpo_linear_bwd_weight(ds2, S[l].f, G[P_L2W], G[P_L2B], R, ff, d, 1.0f, fork.sync(), gate_rng(d3)));
+        // f = drop2(relu(x1 W1^T + b1));  dx1 = ds2 + (df*gate) W1
+        {
+            GemmArgs g;
+            g.A = df; g.B = P[P_L1W]; g.C = dx1; g.residual = ds2;
+            g.M = R; g.N = d; g.K = ff; g.lda = ff; g.ldb = d; g.ldc = d;
+            g.gate = S[l].f; g.gate_mode = MPO_GATE_RELU; g.gate_p = drop_p;
+            RC(mpo_launch_gemm(g, 1, 0, stream));
         }
+        RC(mpo_linear_bwd_weight(df, S[l].x1, G[P_L1W], G[P_L1B], R, d, ff, 1.0f, fork.sync(), gate(S[l].f, MPO_GATE_RELU, drop_p)));
+        // x1 = LN1(s1)
+        RC(mpo_launch_ln_bwd(dx1, S[l].s1, S[l].st1, P[P_N1W], ds1, nullptr, nullptr, R, d, 0, stream));
+        RC(mpo_launch_ln_bwd_params_only(dx1, S[l].s1, S[l].st1, G[P_N1W], G[P_N1B], R, d, fork.sync()));
+        // s1 = in + drop1(o W_o^T + b_o)
+        RC(mpo_linear_bwd_input(ds1, P[P_OUTW], dob, R, d, d, 1.0f, 0, stream, gate_rng(d1)));
+        RC(mpo_linear_bwd_weight(ds1, S[l].o, G[P_OUTW], G[P_OUTB], R, d, d, 1.0f, fork.sync(), gate_rng(d1)));
+        RC(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, n_slides, T, d, heads, stream));
+        // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in
+        {
+            GemmArgs g;
+            g.A = dqkv; g.B = P[P_INW]; g.C = din; g.residual = ds1;
+            g.M = R; g.N = d; g.K = 3 * d; g.lda = 3 * d; g.ldb = d; g.ldc = d;
+            RC(mpo_launch_gemm(g, 1, 0, stream));
+        }
+        RC(mpo_linear_bwd_weight(dqkv, in, G[P_INW], G[P_INB], R, d, 3 * d, 1.0f, fork.sync()));
+        dcur = din;
     }
+    RC(fork.join());
     return 0;
 }
 
@@ -228,19 +246,24 @@ int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const fl
     float* da = ws.floats((size_t)R * d);
     float* db = ws.floats((size_t)R * d);
     MPO_CHECK(dhpool && dscores && dab && da && db, "gated pool backward: workspace too small (%zu bytes)", workspace_bytes);
+    SideFork fork(stream);                                  // weight gradients beside the dx chain (no buffer is rewritten)
     // h = drop(relu(hpool W_rho^T + b_rho))
+    RC(mpo_linear_bwd_weight(dh, hpool, G[6], G[7], n_slides, d, d, 1.0f, fork.sync(), gate(h, MPO_GATE_RELU, rho_drop_p)));
     RC(mpo_linear_bwd_input(dh, P[6], dhpool, n_slides, d, d, 1.0f, 0, stream, gate(h, MPO_GATE_RELU, rho_drop_p)));
-    RC(mpo_linear_bwd_weight(dh, hpool, G[6], G[7], n_slides, d, d, 1.0f, stream, gate(h, MPO_GATE_RELU, rho_drop_p)));
     RC(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, n_slides, L, d, stream));
     // scores = ab W_c^T + b_c
+    RC(mpo_linear_bwd_weight(dscores, ab, G[4], G[5], R, d, 1, 1.0f, fork.sync()));
     RC(mpo_linear_bwd_input(dscores, P[4], dab, R, d, 1, 1.0f, 0, stream));
-    RC(mpo_linear_bwd_weight(dscores, ab, G[4], G[5], R, d, 1, 1.0f, stream));
     RC(mpo_launch_ew_mul(dab, b, da, R * d, stream));
     RC(mpo_launch_ew_mul(dab, a, db, R * d, stream));
+    {
+        hipStream_t ss = fork.sync();
+        RC(mpo_linear_bwd_weight(da, x, G[0], G[1], R, d, d, 1.0f, ss, gate(a, MPO_GATE_TANH, head_drop_p)));
+        RC(mpo_linear_bwd_weight(db, x, G[2], G[3], R, d, d, 1.0f, ss, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
+    }
     RC(mpo_linear_bwd_input(da, P[0], dx, R, d, d, 1.0f, 1, stream, gate(a, MPO_GATE_TANH, head_drop_p)));
-    RC(mpo_linear_bwd_weight(da, x, G[0], G[1], R, d, d, 1.0f, stream, gate(a, MPO_GATE_TANH, head_drop_p)));
     RC(mpo_linear_bwd_input(db, P[2], dx, R, d, d, 1.0f, 1, stream, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
-    RC(mpo_linear_bwd_weight(db, x, G[2], G[3], R, d, d, 1.0f, stream, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
+    RC(fork.join());
     return 0;
 }
 
@@ -285,13 +308,15 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
     float* dz2 = ws.floats((size_t)n_slides * dout);
     float* dz1 = ws.floats((size_t)n_slides * hidden);
     MPO_CHECK(dlogits && dz2 && dz1, "fusion head backward: workspace too small (%zu bytes)", workspace_bytes);
+    SideFork fork(stream);
     RC(mpo_launch_head_bwd(hazards, survs, y, d_hazards, d_survs, d_y, dlogits, n_slides, n_classes, stream));
+    RC(mpo_linear_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f, fork.sync()));
     RC(mpo_linear_bwd_input(dlogits, P[4], dz2, n_slides, dout, n_classes, 1.0f, 0, stream));
-    RC(mpo_linear_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f, stream));
+    RC(mpo_linear_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, fork.sync(), gate(z2, MPO_GATE_RELU)));
     RC(mpo_linear_bwd_input(dz2, P[2], dz1, n_slides, hidden, dout, 1.0f, 0, stream, gate(z2, MPO_GATE_RELU)));
-    RC(mpo_linear_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, stream, gate(z2, MPO_GATE_RELU)));
+    RC(mpo_linear_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, fork.sync(), gate(z1, MPO_GATE_RELU)));
     RC(mpo_linear_bwd_input(dz1, P[0], d_hcat, n_slides, din, hidden, 1.0f, 0, stream, gate(z1, MPO_GATE_RELU)));
-    RC(mpo_linear_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, stream, gate(z1, MPO_GATE_RELU)));
+    RC(fork.join());
     return 0;
 }
 
