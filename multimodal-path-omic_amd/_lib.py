@@ -105,7 +105,10 @@ def prepare_device(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _prepared:
         with torch.cuda.device(idx):
-            check(lib().mpo_prepare_device(0 if os.environ.get("MPO_NO_SIDE_STREAM") else 1), "mpo_prepare_device")
+            # The library side stream (weight gradients beside the dX chain) is OPT-IN: measured r01, forking onto a
+            # library-created stream inside torch's stream capture segfaults hipStreamEndCapture on ROCm 7.2
+            # (eager mode is fine), so the default keeps every launch on the caller's stream.
+            check(lib().mpo_prepare_device(1 if os.environ.get("MPO_SIDE_STREAM") else 0), "mpo_prepare_device")
         _prepared.add(idx)
 
 
