@@ -101,7 +101,8 @@ class GraphedWindowStep:
                 self._body()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, pool=pool):
+        # thread_local: other threads (RCCL's watchdog under torch.distributed) may issue HIP calls meanwhile
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
             self.loss, self.risk = self._body()
 
     def _body(self):
