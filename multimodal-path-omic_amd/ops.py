@@ -237,11 +237,25 @@ class PatchFcFn(torch.autograd.Function):
                                                     L.stream_of(g)), "mpo_patch_epilogue_backward")
         dw, db = (grad_out(p) for p in ctx.param_refs)
         _splitk_tn(g, x, dw)
-        torch.sum(g, 0, dtype=torch.float32, out=db)       # (mpo_colsum_bf16 exists but its atomics are slower: r01)
+        _colsum_two_stage(g, db)
         return None, dw, db, None, None
 
 
-def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk: int = 8192) -> torch.Tensor:
+def _colsum_two_stage(g: torch.Tensor, out: torch.Tensor, block: int = 256) -> torch.Tensor:
+    """Column sums of a tall bf16 matrix in fp32: (rows/256, 256, d) -> sum(1) -> sum(0).  One flat torch.sum over
+    480k rows runs at 1.7-2.4 TB/s (101-142 us); the blocked form takes 56 us (measured r01)."""
+    rows, d = g.shape
+    main = rows // block * block
+    if main:
+        torch.sum(g[:main].view(rows // block, block, d).sum(1, dtype=torch.float32), 0, out=out)
+    else:
+        out.zero_()
+    if main < rows:
+        out += g[main:].sum(0, dtype=torch.float32)
+    return out
+
+
+def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk: int = 4096) -> torch.Tensor:
     """g^T x with the (huge) row dimension split into batches: (S, d, C) @ (S, C, k) -> sum_S, fp32."""
     rows = g.shape[0]
     s = max(1, rows // target_chunk)
