@@ -55,6 +55,19 @@ inline GateSpec gate_rng(DropSpec d) {
 }
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+// Backward entries take `phase`: 1 = the critical data chain only (input gradients; intermediates stay in the
+// workspace), 2 = the weight / LayerNorm-parameter gradients only (reads those intermediates; run it later, e.g. on
+// another stream, with the SAME workspace), 3 = both in one call.
+#define MAIN(expr) do { if (phase & 1) RC(expr); } while (0)
+#define SIDE(expr) do { if (phase & 2) RC(expr); } while (0)
+struct SideSel {                        // stream for the weight-gradient launches of this call
+    SideFork fork;
+    hipStream_t main;
+    int phase;
+    SideSel(hipStream_t s, int ph) : fork(s), main(s), phase(ph) {}
+    hipStream_t get() { return phase == 3 ? fork.sync() : main; }
+    int join() { return phase == 3 ? fork.join() : 0; }
+};
 
 // ------------------------------------------------------------------------------------------- K4 encoder
 enum { P_INW, P_INB, P_OUTW, P_OUTB, P_L1W, P_L1B, P_L2W, P_L2B, P_N1W, P_N1B, P_N2W, P_N2B, P_PER_LAYER };
@@ -131,11 +144,12 @@ int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int 
 
 int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
                          const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
-                         const float* saved, const float* dy, float* dx, float* const* grads,
+                         const float* saved, const float* dy, float* dx, float* const* grads, int phase,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     const int R = n_slides * T;
     const uint64_t stride = enc_stream_stride(n_slides, T, d, ff);
     MPO_CHECK(layers <= 8, "encoder: at most 8 layers (got %d)", layers);
+    MPO_CHECK(phase >= 1 && phase <= 3, "backward phase must be 1, 2 or 3 (got %d)", phase);
     EncLayerSaved S[8];
     Carver c(const_cast<float*>(saved));
     for (int l = 0; l < layers; ++l) enc_carve(c, &S[l], n_slides, T, d, ff, heads);
@@ -143,7 +157,7 @@ int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int
     // The critical chain (LayerNorm / input-gradient GEMMs / attention) runs on the caller's stream; weight-gradient
     // GEMMs and LayerNorm parameter reductions go to the side stream right after their inputs exist.  Nothing is
     // updated in place and every layer has its own buffer set, so the side work only has to be joined at the end.
-    SideFork fork(stream);
+    SideSel side(stream, phase);
     const float* dcur = dy;
     for (int l = layers - 1; l >= 0; --l) {
         float* ds2 = ws.floats((size_t)R * d);
@@ -160,38 +174,38 @@ int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int
         const uint64_t base = offset + stride * 4 * (uint64_t)l;
         const DropSpec d1 = stream_of(drop_p, seed, base, stride, 1, rng_epoch), d3 = stream_of(drop_p, seed, base, stride, 3, rng_epoch);
         // x2 = LN2(s2)
-        RC(mpo_launch_ln_bwd(dcur, S[l].s2, S[l].st2, P[P_N2W], ds2, nullptr, nullptr, R, d, 0, stream));
-        RC(mpo_launch_ln_bwd_params_only(dcur, S[l].s2, S[l].st2, G[P_N2W], G[P_N2B], R, d, fork.sync()));
+        MAIN(mpo_launch_ln_bwd(dcur, S[l].s2, S[l].st2, P[P_N2W], ds2, nullptr, nullptr, R, d, 0, stream));
+        SIDE(mpo_launch_ln_bwd_params_only(dcur, S[l].s2, S[l].st2, G[P_N2W], G[P_N2B], R, d, side.get()));
         // s2 = x1 + drop3(f W2^T + b2)
-        RC(mpo_linear_bwd_input(ds2, P[P_L2W], df, R, ff, d, 1.0f, 0, stream, gate_rng(d3)));
-        RC(mpo_linear_bwd_weight(ds2, S[l].f, G[P_L2W], G[P_L2B], R, ff, d, 1.0f, fork.sync(), gate_rng(d3)));
+        MAIN(mpo_linear_bwd_input(ds2, P[P_L2W], df, R, ff, d, 1.0f, 0, stream, gate_rng(d3)));
+        SIDE(mpo_linear_bwd_weight(ds2, S[l].f, G[P_L2W], G[P_L2B], R, ff, d, 1.0f, side.get(), gate_rng(d3)));
         // f = drop2(relu(x1 W1^T + b1));  dx1 = ds2 + (df*gate) W1
         {
             GemmArgs g;
             g.A = df; g.B = P[P_L1W]; g.C = dx1; g.residual = ds2;
             g.M = R; g.N = d; g.K = ff; g.lda = ff; g.ldb = d; g.ldc = d;
             g.gate = S[l].f; g.gate_mode = MPO_GATE_RELU; g.gate_p = drop_p;
-            RC(mpo_launch_gemm(g, 1, 0, stream));
+            MAIN(mpo_launch_gemm(g, 1, 0, stream));
         }
-        RC(mpo_linear_bwd_weight(df, S[l].x1, G[P_L1W], G[P_L1B], R, d, ff, 1.0f, fork.sync(), gate(S[l].f, MPO_GATE_RELU, drop_p)));
+        SIDE(mpo_linear_bwd_weight(df, S[l].x1, G[P_L1W], G[P_L1B], R, d, ff, 1.0f, side.get(), gate(S[l].f, MPO_GATE_RELU, drop_p)));
         // x1 = LN1(s1)
-        RC(mpo_launch_ln_bwd(dx1, S[l].s1, S[l].st1, P[P_N1W], ds1, nullptr, nullptr, R, d, 0, stream));
-        RC(mpo_launch_ln_bwd_params_only(dx1, S[l].s1, S[l].st1, G[P_N1W], G[P_N1B], R, d, fork.sync()));
+        MAIN(mpo_launch_ln_bwd(dx1, S[l].s1, S[l].st1, P[P_N1W], ds1, nullptr, nullptr, R, d, 0, stream));
+        SIDE(mpo_launch_ln_bwd_params_only(dx1, S[l].s1, S[l].st1, G[P_N1W], G[P_N1B], R, d, side.get()));
         // s1 = in + drop1(o W_o^T + b_o)
-        RC(mpo_linear_bwd_input(ds1, P[P_OUTW], dob, R, d, d, 1.0f, 0, stream, gate_rng(d1)));
-        RC(mpo_linear_bwd_weight(ds1, S[l].o, G[P_OUTW], G[P_OUTB], R, d, d, 1.0f, fork.sync(), gate_rng(d1)));
-        RC(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, n_slides, T, d, heads, stream));
+        MAIN(mpo_linear_bwd_input(ds1, P[P_OUTW], dob, R, d, d, 1.0f, 0, stream, gate_rng(d1)));
+        SIDE(mpo_linear_bwd_weight(ds1, S[l].o, G[P_OUTW], G[P_OUTB], R, d, d, 1.0f, side.get(), gate_rng(d1)));
+        MAIN(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, n_slides, T, d, heads, stream));
         // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in
         {
             GemmArgs g;
             g.A = dqkv; g.B = P[P_INW]; g.C = din; g.residual = ds1;
             g.M = R; g.N = d; g.K = 3 * d; g.lda = 3 * d; g.ldb = d; g.ldc = d;
-            RC(mpo_launch_gemm(g, 1, 0, stream));
+            MAIN(mpo_launch_gemm(g, 1, 0, stream));
         }
-        RC(mpo_linear_bwd_weight(dqkv, in, G[P_INW], G[P_INB], R, d, 3 * d, 1.0f, fork.sync()));
+        SIDE(mpo_linear_bwd_weight(dqkv, in, G[P_INW], G[P_INB], R, d, 3 * d, 1.0f, side.get()));
         dcur = din;
     }
-    RC(fork.join());
+    RC(side.join());
     return 0;
 }
 
@@ -233,8 +247,9 @@ int mpo_gated_pool_forward(const float* x, int n_slides, int L, int d, const flo
 
 int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const float* const* P,
                             float head_drop_p, float rho_drop_p, const float* saved, const float* h,
-                            const float* dh, const float* d_scores_ext, float* dx, float* const* G,
+                            const float* dh, const float* d_scores_ext, float* dx, float* const* G, int phase,
                             void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    MPO_CHECK(phase >= 1 && phase <= 3, "backward phase must be 1, 2 or 3 (got %d)", phase);
     const int R = n_slides * L;
     Carver c(const_cast<float*>(saved));
     const float* a = c.take((size_t)R * d); const float* b = c.take((size_t)R * d); const float* ab = c.take((size_t)R * d);
@@ -246,24 +261,24 @@ int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const fl
     float* da = ws.floats((size_t)R * d);
     float* db = ws.floats((size_t)R * d);
     MPO_CHECK(dhpool && dscores && dab && da && db, "gated pool backward: workspace too small (%zu bytes)", workspace_bytes);
-    SideFork fork(stream);                                  // weight gradients beside the dx chain (no buffer is rewritten)
+    SideSel side(stream, phase);                            // weight gradients beside the dx chain (no buffer is rewritten)
     // h = drop(relu(hpool W_rho^T + b_rho))
-    RC(mpo_linear_bwd_weight(dh, hpool, G[6], G[7], n_slides, d, d, 1.0f, fork.sync(), gate(h, MPO_GATE_RELU, rho_drop_p)));
-    RC(mpo_linear_bwd_input(dh, P[6], dhpool, n_slides, d, d, 1.0f, 0, stream, gate(h, MPO_GATE_RELU, rho_drop_p)));
-    RC(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, n_slides, L, d, stream));
+    SIDE(mpo_linear_bwd_weight(dh, hpool, G[6], G[7], n_slides, d, d, 1.0f, side.get(), gate(h, MPO_GATE_RELU, rho_drop_p)));
+    MAIN(mpo_linear_bwd_input(dh, P[6], dhpool, n_slides, d, d, 1.0f, 0, stream, gate(h, MPO_GATE_RELU, rho_drop_p)));
+    MAIN(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, n_slides, L, d, stream));
     // scores = ab W_c^T + b_c
-    RC(mpo_linear_bwd_weight(dscores, ab, G[4], G[5], R, d, 1, 1.0f, fork.sync()));
-    RC(mpo_linear_bwd_input(dscores, P[4], dab, R, d, 1, 1.0f, 0, stream));
-    RC(mpo_launch_ew_mul(dab, b, da, R * d, stream));
-    RC(mpo_launch_ew_mul(dab, a, db, R * d, stream));
+    SIDE(mpo_linear_bwd_weight(dscores, ab, G[4], G[5], R, d, 1, 1.0f, side.get()));
+    MAIN(mpo_linear_bwd_input(dscores, P[4], dab, R, d, 1, 1.0f, 0, stream));
+    MAIN(mpo_launch_ew_mul(dab, b, da, R * d, stream));
+    MAIN(mpo_launch_ew_mul(dab, a, db, R * d, stream));
     {
-        hipStream_t ss = fork.sync();
-        RC(mpo_linear_bwd_weight(da, x, G[0], G[1], R, d, d, 1.0f, ss, gate(a, MPO_GATE_TANH, head_drop_p)));
-        RC(mpo_linear_bwd_weight(db, x, G[2], G[3], R, d, d, 1.0f, ss, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
+        hipStream_t ss = side.get();
+        SIDE(mpo_linear_bwd_weight(da, x, G[0], G[1], R, d, d, 1.0f, ss, gate(a, MPO_GATE_TANH, head_drop_p)));
+        SIDE(mpo_linear_bwd_weight(db, x, G[2], G[3], R, d, d, 1.0f, ss, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
     }
-    RC(mpo_linear_bwd_input(da, P[0], dx, R, d, d, 1.0f, 1, stream, gate(a, MPO_GATE_TANH, head_drop_p)));
-    RC(mpo_linear_bwd_input(db, P[2], dx, R, d, d, 1.0f, 1, stream, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
-    RC(fork.join());
+    MAIN(mpo_linear_bwd_input(da, P[0], dx, R, d, d, 1.0f, 1, stream, gate(a, MPO_GATE_TANH, head_drop_p)));
+    MAIN(mpo_linear_bwd_input(db, P[2], dx, R, d, d, 1.0f, 1, stream, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
+    RC(side.join());
     return 0;
 }
 
@@ -299,8 +314,9 @@ int mpo_fusion_head_forward(const float* hcat, int n_slides, int din, int hidden
 int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
                              const float* const* P, const float* saved, const float* hazards, const float* survs,
                              const float* y, const float* d_hazards, const float* d_survs, const float* d_y,
-                             float* d_hcat, float* const* G, void* workspace, size_t workspace_bytes,
+                             float* d_hcat, float* const* G, int phase, void* workspace, size_t workspace_bytes,
                              mpo_stream_t stream) {
+    MPO_CHECK(phase >= 1 && phase <= 3, "backward phase must be 1, 2 or 3 (got %d)", phase);
     Carver c(const_cast<float*>(saved));
     const float* z1 = c.take((size_t)n_slides * hidden); const float* z2 = c.take((size_t)n_slides * dout);
     Arena ws(workspace, workspace_bytes);
@@ -308,15 +324,15 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
     float* dz2 = ws.floats((size_t)n_slides * dout);
     float* dz1 = ws.floats((size_t)n_slides * hidden);
     MPO_CHECK(dlogits && dz2 && dz1, "fusion head backward: workspace too small (%zu bytes)", workspace_bytes);
-    SideFork fork(stream);
-    RC(mpo_launch_head_bwd(hazards, survs, y, d_hazards, d_survs, d_y, dlogits, n_slides, n_classes, stream));
-    RC(mpo_linear_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f, fork.sync()));
-    RC(mpo_linear_bwd_input(dlogits, P[4], dz2, n_slides, dout, n_classes, 1.0f, 0, stream));
-    RC(mpo_linear_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, fork.sync(), gate(z2, MPO_GATE_RELU)));
-    RC(mpo_linear_bwd_input(dz2, P[2], dz1, n_slides, hidden, dout, 1.0f, 0, stream, gate(z2, MPO_GATE_RELU)));
-    RC(mpo_linear_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, fork.sync(), gate(z1, MPO_GATE_RELU)));
-    RC(mpo_linear_bwd_input(dz1, P[0], d_hcat, n_slides, din, hidden, 1.0f, 0, stream, gate(z1, MPO_GATE_RELU)));
-    RC(fork.join());
+    SideSel side(stream, phase);
+    MAIN(mpo_launch_head_bwd(hazards, survs, y, d_hazards, d_survs, d_y, dlogits, n_slides, n_classes, stream));
+    SIDE(mpo_linear_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f, side.get()));
+    MAIN(mpo_linear_bwd_input(dlogits, P[4], dz2, n_slides, dout, n_classes, 1.0f, 0, stream));
+    SIDE(mpo_linear_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, side.get(), gate(z2, MPO_GATE_RELU)));
+    MAIN(mpo_linear_bwd_input(dz2, P[2], dz1, n_slides, hidden, dout, 1.0f, 0, stream, gate(z2, MPO_GATE_RELU)));
+    SIDE(mpo_linear_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, side.get(), gate(z1, MPO_GATE_RELU)));
+    MAIN(mpo_linear_bwd_input(dz1, P[0], d_hcat, n_slides, din, hidden, 1.0f, 0, stream, gate(z1, MPO_GATE_RELU)));
+    RC(side.join());
     return 0;
 }
 

@@ -35,10 +35,17 @@ class FlatGradBucket:
             off += p.numel()
 
     def begin(self):
+        import os
+        from . import ops
+        ops.defer_weight_grads = self.flat.is_cuda and not os.environ.get("MPO_NO_DEFER")
         for p in self.params:
             p.grad = None
 
     def finish(self):
+        from . import ops
+        if self.flat.is_cuda:
+            ops.join_deferred(self.flat.device)          # weight gradients written on the deferred stream
+        ops.defer_weight_grads = False
         for p in self.params:
             view = p._mpo_grad_view
             if p.grad is None:

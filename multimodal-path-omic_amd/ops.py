@@ -93,6 +93,51 @@ def _epoch():
     return L.ptr(_rng_epoch_tensor) if _rng_epoch_tensor is not None else None
 
 
+# ---- deferred weight-gradient work (phase 2 of the tail backward entries)
+_defer_stream = {}
+# Only the window harness turns this on (FlatGradBucket.begin .. finish brackets it and joins the stream):
+# a plain caller reads gradients on its own stream right after backward() and must not race a second stream.
+defer_weight_grads = False
+
+
+def _grads_in_bucket(params, grads):
+    return all(getattr(p, "_mpo_grad_view", None) is not None and g.data_ptr() == p._mpo_grad_view.data_ptr()
+               for p, g in zip(params, grads))
+
+
+def _two_phase(call, ws, device, params=(), grads=()):
+    """Run a backward entry as phase 1 (data chain) on the current stream and phase 2 (weight gradients) on a
+    second stream that waits for phase 1: the weight-gradient GEMMs then overlap whatever the main stream does
+    next (upstream layers, the HBM-bound co-attention / patch-layer backward).  join_deferred() -- called by
+    FlatGradBucket.finish() -- makes the main stream wait for them before the gradients are used."""
+    if not defer_weight_grads or not _grads_in_bucket(params, grads):
+        call(3)             # (a fresh gradient tensor is accumulated by autograd on THIS stream: no deferral)
+        return
+    main = torch.cuda.current_stream(device)
+    side = _defer_stream.get(device)
+    if side is None:
+        side = _defer_stream[device] = torch.cuda.Stream(device=device)
+    call(1)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        call(2)
+    ws.record_stream(side)
+
+
+def _keep_for_side(t):
+    """Tensors read by deferred phase-2 work must not be recycled by the allocator before that work ran."""
+    if defer_weight_grads and t is not None and t.is_cuda:
+        side = _defer_stream.get(t.device)
+        if side is not None:
+            t.record_stream(side)
+
+
+def join_deferred(device):
+    side = _defer_stream.get(device)
+    if side is not None:
+        torch.cuda.current_stream(device).wait_stream(side)
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -371,9 +416,12 @@ class EncoderFn(torch.autograd.Function):
         grads = [grad_out(p) for p in ctx.param_refs]
         ws = _workspace(lib.mpo_encoder_workspace_bytes(n_slides, T, d, ff), x.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
-        L.check(lib.mpo_encoder_backward(L.ptr(x), n_slides, T, d, ff, heads, layers, pa, drop_p, seed, off,
-                                         _epoch(), L.ptr(saved), L.ptr(dy.contiguous()), L.ptr(dx), ga, L.ptr(ws), ws.numel(),
-                                         L.stream_of(x)), "mpo_encoder_backward")
+        dy = dy.contiguous()
+        _two_phase(lambda ph: L.check(lib.mpo_encoder_backward(
+            L.ptr(x), n_slides, T, d, ff, heads, layers, pa, drop_p, seed, off, _epoch(), L.ptr(saved), L.ptr(dy),
+            L.ptr(dx), ga, ph, L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_encoder_backward"), ws, x.device, ctx.param_refs, grads)
+        for t in (dy, saved, x):
+            _keep_for_side(t)
         return (dx, None, None, *grads)
 
 
@@ -424,11 +472,13 @@ class GatedPoolFn(torch.autograd.Function):
             dh = torch.zeros_like(h)
         ws = _workspace(lib.mpo_gated_pool_workspace_bytes(n_slides, Lr, d), x.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
-        L.check(lib.mpo_gated_pool_backward(L.ptr(x), n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h),
-                                            L.ptr(dh.contiguous()),
-                                            L.ptr(d_scores.contiguous()) if d_scores is not None else None,
-                                            L.ptr(dx), ga, L.ptr(ws), ws.numel(), L.stream_of(x)),
-                "mpo_gated_pool_backward")
+        dh = dh.contiguous()
+        d_sc = d_scores.contiguous() if d_scores is not None else None
+        _two_phase(lambda ph: L.check(lib.mpo_gated_pool_backward(
+            L.ptr(x), n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h), L.ptr(dh), L.ptr(d_sc), L.ptr(dx), ga, ph,
+            L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_gated_pool_backward"), ws, x.device, ctx.param_refs, grads)
+        for t in (dh, saved, x, h):
+            _keep_for_side(t)
         return (dx, None, None, None, *grads)
 
 
@@ -522,10 +572,13 @@ class FusionHeadFn(torch.autograd.Function):
         grads = [grad_out(p) for p in ctx.param_refs]
         ws = _workspace(lib.mpo_fusion_head_workspace_bytes(b, hidden, dout, c), hcat.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
-        opt = lambda t: L.ptr(t.contiguous()) if t is not None else None  # noqa: E731
-        L.check(lib.mpo_fusion_head_backward(L.ptr(hcat), b, din, hidden, dout, c, pa, L.ptr(saved), L.ptr(hz), L.ptr(sv),
-                                             L.ptr(y), opt(dhz), opt(dsv), opt(dy), L.ptr(d_hcat), ga, L.ptr(ws),
-                                             ws.numel(), L.stream_of(hcat)), "mpo_fusion_head_backward")
+        dhz, dsv, dy = (t.contiguous() if t is not None else None for t in (dhz, dsv, dy))
+        _two_phase(lambda ph: L.check(lib.mpo_fusion_head_backward(
+            L.ptr(hcat), b, din, hidden, dout, c, pa, L.ptr(saved), L.ptr(hz), L.ptr(sv), L.ptr(y), L.ptr(dhz), L.ptr(dsv),
+            L.ptr(dy), L.ptr(d_hcat), ga, ph, L.ptr(ws), ws.numel(), L.stream_of(hcat)), "mpo_fusion_head_backward"),
+            ws, hcat.device, ctx.param_refs, grads)
+        for t in (saved, hcat):
+            _keep_for_side(t)
         return (d_hcat, *grads)
 
 
