@@ -659,9 +659,18 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
             _epoch(), L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
             L.ptr(d_query), L.ptr(d_k), L.ptr(d_tk), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
             L.ptr(d_out_b), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
-        # back through the caller-side GEMM  K = H W_k^T + b_k
-        d_h = torch.addmm(d_h.float(), d_k, in_w[E:2 * E]).to(bag_data.dtype)
-        d_in_w[E:2 * E] = torch.mm(d_k.t(), bag_data.float())
+        # back through the caller-side GEMM  K = H W_k^T + b_k.  The forward K stays fp32 (the gate amplifies its
+        # rounding); its GRADIENT goes through bf16 operands with fp32 accumulation for a bf16 bag: dW_k as a
+        # batched split-K product (one 480 000-deep fp32 contraction took 1.19 ms in rocBLAS), dH += dK W_k as a
+        # bf16 GEMM (0.59 ms in fp32).
+        w_k = in_w[E:2 * E]
+        if bag_data.dtype == torch.bfloat16:
+            dk16 = d_k.to(torch.bfloat16)
+            d_h = torch.addmm(d_h, dk16, w_k.to(torch.bfloat16))
+            _splitk_tn(dk16, bag_data, d_in_w[E:2 * E])
+        else:
+            d_h = torch.addmm(d_h, d_k, w_k)
+            d_in_w[E:2 * E] = torch.mm(d_k.t(), bag_data)
         d_in_b[E:2 * E] = d_k.sum(0)
         return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None
 
