@@ -81,8 +81,10 @@ def test_nacagat_forward_backward(dev, golden, case, dtype):
     gs = torch.autograd.grad((out * p_out.to(dev)).sum() + (a * p_a.to(dev)).sum(), tensors)
     for n, gr in zip(names, gs):
         tol = 1e-2 if peaky else 2e-3
-        if n == "bag" and not f32:
-            tol = 1.5e-2                                        # d_bag is emitted in bf16
+        if not f32:
+            # bf16 bag: d_bag is emitted in bf16 and the key-projection gradients (dW_k, dH += dK W_k) run
+            # through bf16 operands with fp32 accumulation
+            tol = 1.5e-2 if n == "bag" else max(tol, 5e-3)
         e = relerr(gr, g1_o[n])
         assert e < tol, (n, e)
     if f32:
