@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--patches", type=int, default=15000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--n-windows", type=int, default=2, help="distinct resident windows cycled (working set >> 256 MB L3)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="BASELINE cfg 4: bag lengths drawn uniformly from [2000, 30000] (fixed multiset, length-aware "
+                         "assignment of each window's slides to ranks) instead of --patches for every slide")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured HIP graph")
     return ap.parse_args()
@@ -47,19 +50,28 @@ def build_model(kind, dev, bag_dtype):
     return cls(omic_sizes=[256] * 6, model_size="medium", bag_dtype=bag_dtype).to(dev).train()
 
 
-def make_windows(n_windows, window, patches, dev, bag_dtype, seed):
+def make_windows(n_windows, window, patches, dev, bag_dtype, seed, ragged=False, rank=0, world=1):
     """Synthetic N(0,1) patch features generated on the device (seeded), labels/censorship cycling
-    (i mod 4, i mod 2) as SURVEY 8(d) prescribes."""
+    (i mod 4, i mod 2) as SURVEY 8(d) prescribes.  ragged: every window is a fixed multiset of world*window bag
+    lengths in [2000, 30000] (the same at every GPU count for a given global window), dealt to the ranks by
+    dp.assign_slides (longest-first bin packing on patch count); this rank keeps its share."""
+    from multimodal_path_omic_amd.dp import assign_slides
     from multimodal_path_omic_amd.ops import BagBatch, make_cu
+    from multimodal_path_omic_amd.synthetic import slide_lengths
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     out = []
     for w in range(n_windows):
-        data = torch.randn(window * patches, 1024, device=dev, dtype=torch.float32, generator=g).to(bag_dtype)
-        lengths = [patches] * window
+        if ragged:
+            all_len = slide_lengths(world * window, 2000, 30000, 4321 + w)
+            lengths = [all_len[i] for i in assign_slides(all_len, world)[rank]]
+        else:
+            lengths = [patches] * window
+        window_n = len(lengths)
+        data = torch.randn(sum(lengths), 1024, device=dev, dtype=torch.float32, generator=g).to(bag_dtype)
         bags = BagBatch(data, make_cu(lengths, dev), lengths)
-        omics = [torch.randn(window, 256, device=dev, generator=g) for _ in range(6)]
-        idx = torch.arange(window, device=dev) + w * window
+        omics = [torch.randn(window_n, 256, device=dev, generator=g) for _ in range(6)]
+        idx = torch.arange(window_n, device=dev) + w * window
         out.append((bags, omics, idx % 4, (idx % 2).float()))
     return out
 
@@ -68,22 +80,24 @@ def roofline_leg(dev, window, patches, bag_dtype, reps=20):
     """Time the K1 forward bag-pass kernel alone (HIP events on the launching stream) over a window
     of H_bag-like bags; algorithmic bytes = M*d*e per slide."""
     from multimodal_path_omic_amd import _lib as L
-    from multimodal_path_omic_amd.ops import make_cu
+    from multimodal_path_omic_amd.ops import BagBatch, make_cu
     E, n_q = 256, 6
     esz = 2 if bag_dtype == torch.bfloat16 else 4
     lengths = [patches] * window
     cu = make_cu(lengths, dev)
     bags = [torch.relu(torch.randn(window * patches, E, device=dev)).to(bag_dtype) for _ in range(2)]
+    batch = BagBatch(bags[0], cu, lengths)
+    plan = batch.plan()
     qk2 = torch.randn(window * n_q, E, device=dev) * 0.05
     lib = L.lib()
-    splits = lib.mpo_coattn_splits(window, patches)
-    part_ml = torch.empty(window * splits * 32, device=dev)
-    part_ctx = torch.empty(window * splits * n_q * E, device=dev)
+    parts = lib.mpo_coattn_target_workgroups() + window
+    part_ml = torch.empty(parts * 32, device=dev)
+    part_ctx = torch.empty(parts * n_q * E, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     def launch(i):
         L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), L.bag_dtype_code(bags[0]), L.ptr(cu), window, E,
-                                           L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, splits,
+                                           L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, patches, plan,
                                            stream.cuda_stream), "mpo_coattn_fwd_bagpass")
     for i in range(3):
         launch(i)
@@ -160,7 +174,9 @@ def main():
     model = build_model(a.model, dev, bag_dtype)
     bucket = FlatGradBucket(list(model.parameters()))
     opt = FlatAdam(bucket, lr=2e-4, weight_decay=1e-5)            # adam, lr 2e-4, wd 1e-5: config.yaml:57-63
-    windows = make_windows(a.n_windows, a.window, a.patches, dev, bag_dtype, seed=1234 + rank)
+    windows = make_windows(a.n_windows, a.window, a.patches, dev, bag_dtype, seed=1234 + rank, ragged=a.ragged,
+                           rank=rank, world=world)
+    slides_per_step = [len(w[0].lengths) for w in windows]
 
     def eager_step(i):
         bags, omics, labels, cens = windows[i % len(windows)]
@@ -210,14 +226,18 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        slides = world * a.window * a.steps
+        if a.ragged:          # ranks hold different slide counts per window; the global window is world * window slides
+            slides = sum(world * a.window for i in range(a.steps))
+        else:
+            slides = world * a.window * a.steps
         out = {
             "metric": "slides/sec (fwd+bwd) at 15k-patch bags", "value": round(slides / dt, 2), "unit": "slides/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{a.model.upper()} medium whole model fwd+bwd+Adam, {a.patches}x1024 {a.dtype} patch bag "
                                    f"+ 6x256 omic tokens per slide, ces loss", "slides_per_rank_per_step": a.window,
-                       "global_slides_per_step": world * a.window, "patches_per_slide": a.patches,
+                       "global_slides_per_step": world * a.window,
+                       "patches_per_slide": "uniform[2000,30000] (fixed multiset)" if a.ragged else a.patches,
                        "parallelism": f"dp{world}", "resident_windows": a.n_windows, "launch": graph_note},
         }
         out["roofline"] = roofline_leg(dev, a.window, a.patches, bag_dtype)

@@ -32,6 +32,19 @@ extern "C" {
 typedef struct ihipStream_t* mpo_stream_t;   /* == hipStream_t */
 
 enum { MPO_F32 = 0, MPO_BF16 = 1 };
+
+/* Work plan of the bag passes over a ragged window (optional; NULL = every slide is cut into the same number of row
+ * ranges, mpo_coattn_splits()).  With a plan every workgroup gets `rows_per_wg` rows (a multiple of 32) and slide b owns
+ * workgroups wg_start[b] .. wg_start[b+1]-1 = ceil(M_b / rows_per_wg) of them: work proportional to the bag length, so a
+ * window of 2k..30k-patch bags is balanced.  Choose rows_per_wg = round_up_32(ceil(total_rows / T)) with
+ * T = mpo_coattn_target_workgroups() (one workgroup per CU); n_wg = wg_start[n_slides] <= T + n_slides.
+ * wg_start is a DEVICE int32 array of n_slides + 1 entries; the struct itself is host memory. */
+typedef struct mpo_bag_plan {
+    const int32_t* wg_start;
+    int32_t n_wg;
+    int32_t rows_per_wg;
+} mpo_bag_plan;
+int mpo_coattn_target_workgroups(void);
 enum { MPO_ACT_NONE_ = 0, MPO_ACT_RELU_ = 1, MPO_ACT_ELU_ = 2, MPO_ACT_TANH_ = 3, MPO_ACT_SIGMOID_ = 4 };
 
 int mpo_abi_version(void);
@@ -66,7 +79,7 @@ int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_ro
                             const float* query, int n_q, int embed,
                             const float* in_proj_weight, const float* in_proj_bias,
                             const float* out_proj_weight, const float* out_proj_bias,
-                            float* out, float* attn_map, float* saved,
+                            float* out, float* attn_map, float* saved, const mpo_bag_plan* plan /* nullable */,
                             void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 /* d_attn_map (nullable): gradient arriving on the returned map; needs attn_map from the forward.
  * d_bag has the bag's dtype.  d_in_proj_bias[embed..2*embed) (the key bias) is exactly zero: a key
@@ -80,7 +93,8 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                              float* d_query, void* d_bag,
                              float* d_in_proj_weight, float* d_in_proj_bias,
                              float* d_out_proj_weight, float* d_out_proj_bias,
-                             float bag_relu_gate, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+                             float bag_relu_gate, const mpo_bag_plan* plan /* nullable */,
+                             void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 /* bag_relu_gate: 0, or 1/(1-p) when the (bf16) bag is H = dropout_p(relu(.)) as in models/mcat/mcat.py:24-29,87 and
  * the caller wants d_bag already multiplied by that epilogue's derivative (H > 0 ? 1/(1-p) : 0): the H tile is still
  * in LDS when dH is formed, which saves two passes over the bag gradient. */
@@ -123,7 +137,8 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
                                const float* out_proj_weight, const float* out_proj_bias,
                                float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                void* tkbag, float* q_proj, float* out, float* attn_map, float* score_maps,
-                               float* saved, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+                               float* saved, const mpo_bag_plan* plan /* nullable */,
+                               void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype, const void* hbag, int bag_dtype,
                                 const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
                                 const float* query, int n_q, int embed,
@@ -133,7 +148,7 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
                                 float* d_query, void* d_kbag, void* d_tk_scratch, void* d_hbag,
                                 float* d_in_proj_weight, float* d_in_proj_bias,
-                                float* d_out_proj_weight, float* d_out_proj_bias,
+                                float* d_out_proj_weight, float* d_out_proj_bias, const mpo_bag_plan* plan /* nullable */,
                                 void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ==== the 6 x d token tail.  Parameter and gradient tensors are passed as arrays of device pointers in
@@ -216,15 +231,15 @@ int mpo_omic_snn_backward(const float* const* x, const int* widths, int n_groups
 
 /* ---- the two bag-pass kernels of K1 on their own (bench.py times them with HIP events for the
  * roofline line; tests use them for kernel-level checks).  qk2 = log2(e) * (q/sqrt(E)) W_k, [n_slides*n_q, embed].
- * part_ml [n_slides*splits*32], part_ctx [n_slides*splits*n_q*embed] with splits = mpo_coattn_splits(). */
+ * part_ml [P*32], part_ctx / part_dqk [P*n_q*embed] with P >= mpo_coattn_target_workgroups() + n_slides partials. */
 int mpo_coattn_splits(int n_slides, int max_rows);
 int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
                            const float* qk2, float* part_ml, float* part_ctx, float* raw_logits /* nullable */,
-                           int n_q, int splits, mpo_stream_t stream);
+                           int n_q, int max_rows, const mpo_bag_plan* plan /* nullable */, mpo_stream_t stream);
 int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
                            const float* qk2, const float* lse2, const float* dctx, const float* delta,
                            const float* d_attn_map /* nullable */, void* d_bag, float* part_dqk,
-                           int n_q, int splits, mpo_stream_t stream);
+                           int n_q, int max_rows, const mpo_bag_plan* plan /* nullable */, mpo_stream_t stream);
 
 #ifdef __cplusplus
 }

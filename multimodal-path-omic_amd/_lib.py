@@ -16,6 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpo_hip.so")
 
 MPO_F32, MPO_BF16 = 0, 1
+
+
+class BagPlanC(ctypes.Structure):
+    """mpo_bag_plan of include/mpo_hip.h (host struct; wg_start is a device pointer)."""
+    _fields_ = [("wg_start", c_void_p), ("n_wg", ctypes.c_int32), ("rows_per_wg", ctypes.c_int32)]
 ACT = {"none": 0, "relu": 1, "elu": 2, "tanh": 3, "sigmoid": 4}
 
 _lib = None
@@ -28,14 +33,15 @@ _SIGNATURES = {
     "mpo_linear_backward_input": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "mpo_linear_backward_weight": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "mpo_coattn_splits": (c_int, [c_int, c_int]),
-    "mpo_coattn_fwd_bagpass": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P]),
-    "mpo_coattn_bwd_bagpass": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "mpo_coattn_target_workgroups": (c_int, []),
+    "mpo_coattn_fwd_bagpass": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "mpo_coattn_bwd_bagpass": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "mpo_coattn_saved_floats": (c_size_t, [c_int, c_int, c_int]),
     "mpo_coattn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mpo_coattn_mcat_forward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
-                                        _P, _P, _P, _P, c_size_t, _P]),
+                                        _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
-                                         _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+                                         _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
     "mpo_prepare_device": (c_int, [c_int]),
     "mpo_colsum_bf16": (c_int, [_P, _P, ctypes.c_int64, c_int, _P]),
     "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
@@ -44,10 +50,10 @@ _SIGNATURES = {
     "mpo_nacagat_saved_floats": (c_size_t, [c_int, c_int, c_int]),
     "mpo_nacagat_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "mpo_coattn_nacagat_forward": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
-                                           c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                           c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_nacagat_backward": (c_int, [_P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
                                             c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P,
-                                            _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_encoder_saved_floats": (c_size_t, [c_int] * 6),
     "mpo_encoder_workspace_bytes": (c_size_t, [c_int] * 4),
     "mpo_encoder_rng_span": (c_uint64, [c_int] * 5),

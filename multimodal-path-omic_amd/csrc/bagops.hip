@@ -27,18 +27,15 @@ struct BagCfg {
 };
 
 struct SplitGeom {
-    int row_begin, m_rows, r0, r1, n_my;
+    int b, row_begin, m_rows, r0, r1, n_my;
+    size_t part;
 };
 template <int WAVES>
-__device__ __forceinline__ SplitGeom split_geom(const int* cu, int b, int split, int splits, int wave) {
+__device__ __forceinline__ SplitGeom split_geom(const int* cu, const BagPlan& plan, int wave) {
+    const WgGeom g = wg_geom(cu, plan);
     SplitGeom s;
-    s.row_begin = cu[b];
-    s.m_rows = cu[b + 1] - s.row_begin;
-    const int rps = ((s.m_rows + splits - 1) / splits + kTileRows - 1) / kTileRows * kTileRows;
-    s.r0 = split * rps;
-    s.r1 = min(s.m_rows, s.r0 + rps);
-    const int ntiles = s.r1 > s.r0 ? (s.r1 - s.r0 + kTileRows - 1) / kTileRows : 0;
-    s.n_my = wave < ntiles ? (ntiles - wave + WAVES - 1) / WAVES : 0;
+    s.b = g.b; s.row_begin = g.row_begin; s.m_rows = g.m_rows; s.r0 = g.r0; s.r1 = g.r1; s.part = g.part;
+    s.n_my = wave < g.ntiles ? (g.ntiles - wave + WAVES - 1) / WAVES : 0;
     return s;
 }
 
@@ -46,14 +43,14 @@ __device__ __forceinline__ SplitGeom split_geom(const int* cu, int b, int split,
 template <int E_, bool F32BAG>
 __global__ __launch_bounds__((BagCfg<E_, F32BAG>::WAVES * 64), 1)
 void bag_rowdot_kernel(const void* __restrict__ bag_, const int* __restrict__ cu, const float* __restrict__ r,
-                       float* __restrict__ map, float alpha, int n_q, int splits) {
+                       float* __restrict__ map, float alpha, int n_q, BagPlan plan) {
     using G = TileGeom<E_>;
     using C = BagCfg<E_, F32BAG>;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    const SplitGeom sg = split_geom<C::WAVES>(cu, b, blockIdx.x, splits, wave);
+    const SplitGeom sg = split_geom<C::WAVES>(cu, plan, wave);
+    const int b = sg.b;
     char* thi = lds + wave * C::WAVE_LDS;
     char* tlo = thi + (C::NT - 1) * G::TILEB;
     const int q = lane & 15, g = lane >> 4;
@@ -94,14 +91,13 @@ void bag_rowdot_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 template <int E_, bool F32BAG>
 __global__ __launch_bounds__((BagCfg<E_, F32BAG>::WAVES * 64), 1)
 void bag_colacc_kernel(const void* __restrict__ bag_, const int* __restrict__ cu, const float* __restrict__ wmap,
-                       float* __restrict__ part, int n_q, int splits) {
+                       float* __restrict__ part, int n_q, BagPlan plan) {
     using G = TileGeom<E_>;
     using C = BagCfg<E_, F32BAG>;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y, split = blockIdx.x;
-    const SplitGeom sg = split_geom<C::WAVES>(cu, b, split, splits, wave);
+    const SplitGeom sg = split_geom<C::WAVES>(cu, plan, wave);
     char* thi = lds + wave * C::WAVE_LDS;
     char* tlo = thi + (C::NT - 1) * G::TILEB;
     const int q = lane & 15, g = lane >> 4;
@@ -144,7 +140,7 @@ void bag_colacc_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
         for (int t = 0; t < G::DT; ++t) *reinterpret_cast<f32x4*>(wq + q * E_ + 16 * t + 4 * g) = acc[t];
     }
     __syncthreads();
-    const size_t pbase = (size_t)b * splits + split;
+    const size_t pbase = sg.part;
     for (int idx = threadIdx.x; idx < n_q * E_; idx += C::WAVES * 64) {
         float a = 0.f;
 #pragma unroll
@@ -159,15 +155,15 @@ template <int E_, bool OUT_F32>
 __global__ __launch_bounds__(256, 1)
 void bag_outer_kernel(const int* __restrict__ cu, const float* __restrict__ w1, const float* __restrict__ z1,
                       const float* __restrict__ w2, const float* __restrict__ z2, void* __restrict__ dx_,
-                      int n_q, int splits) {
+                      int n_q, BagPlan plan) {
     using G = TileGeom<E_>;
     constexpr int EB = OUT_F32 ? 4 : 2;
     constexpr int IMG = kTileRows * E_ * EB;
     __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    const SplitGeom sg = split_geom<4>(cu, b, blockIdx.x, splits, wave);
+    const SplitGeom sg = split_geom<4>(cu, plan, wave);
+    const int b = sg.b;
     char* img = lds + wave * IMG;
     const int c16 = lane & 15, g = lane >> 4;
     const float* z1b = z1 + (size_t)b * n_q * E_;
@@ -509,36 +505,39 @@ int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, siz
     }
 
 int mpo_launch_bag_rowdot(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* r,
-                          float* map, float alpha, int n_q, int splits, hipStream_t stream) {
-    dim3 grid(splits, n_slides);
+                          float* map, float alpha, int n_q, const BagPlan& plan, hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
     if (bag_f32) {
-        MPO_E_SWITCH(embed, (bag_rowdot_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, r, map, alpha, n_q, splits)))
+        MPO_E_SWITCH(embed, (bag_rowdot_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, r, map, alpha, n_q, plan)))
     } else {
-        MPO_E_SWITCH(embed, (bag_rowdot_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, r, map, alpha, n_q, splits)))
+        MPO_E_SWITCH(embed, (bag_rowdot_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, r, map, alpha, n_q, plan)))
     }
     MPO_LAUNCH_CHECK();
     return 0;
 }
 
 int mpo_launch_bag_colacc(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* wmap,
-                          float* part, int n_q, int splits, hipStream_t stream) {
-    dim3 grid(splits, n_slides);
+                          float* part, int n_q, const BagPlan& plan, hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
     if (bag_f32) {
-        MPO_E_SWITCH(embed, (bag_colacc_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, wmap, part, n_q, splits)))
+        MPO_E_SWITCH(embed, (bag_colacc_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, wmap, part, n_q, plan)))
     } else {
-        MPO_E_SWITCH(embed, (bag_colacc_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, wmap, part, n_q, splits)))
+        MPO_E_SWITCH(embed, (bag_colacc_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, wmap, part, n_q, plan)))
     }
     MPO_LAUNCH_CHECK();
     return 0;
 }
 
 int mpo_launch_bag_outer(const int* cu, int n_slides, int embed, const float* w1, const float* z1, const float* w2,
-                         const float* z2, void* dx, int out_f32, int n_q, int splits, hipStream_t stream) {
-    dim3 grid(splits, n_slides);
+                         const float* z2, void* dx, int out_f32, int n_q, const BagPlan& plan, hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
     if (out_f32) {
-        MPO_E_SWITCH(embed, (bag_outer_kernel<EV, true><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, splits)))
+        MPO_E_SWITCH(embed, (bag_outer_kernel<EV, true><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, plan)))
     } else {
-        MPO_E_SWITCH(embed, (bag_outer_kernel<EV, false><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, splits)))
+        MPO_E_SWITCH(embed, (bag_outer_kernel<EV, false><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, plan)))
     }
     MPO_LAUNCH_CHECK();
     return 0;

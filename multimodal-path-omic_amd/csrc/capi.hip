@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "../../include/mpo_hip.h"
+#include "coattn_tile.h"
 #include "mpo_common.h"
 #include "mpo_kernels.h"
 
@@ -89,11 +90,21 @@ extern "C" int mpo_prepare_device(int enable_side_stream) {
     return 0;
 }
 
+// ONE workgroup per CU over the window (256 CUs): long row ranges amortise the per-workgroup prologue
+// (query fragments) and epilogue (LDS merge, partial write); measured r01 on 32 x 15k bf16:
+// 256 WGs 51.6 us, 512 59.0, 1024 73.0, 2048 98.9.
+extern "C" int mpo_coattn_target_workgroups(void) {
+    static const int target = [] {
+        const char* e = getenv("MPO_COATTN_TARGET_WGS");
+        int t = e ? atoi(e) : 256;
+        return t < 1 ? 1 : (t > 1024 ? 1024 : t);
+    }();
+    return target;
+}
+
 extern "C" int mpo_coattn_splits(int n_slides, int max_rows) {
-    // ONE workgroup per CU over the window (256 CUs): long row ranges amortise the per-workgroup prologue
-    // (query fragments) and epilogue (LDS merge, partial write); measured r01 on 32 x 15k bf16:
-    // 256 WGs 51.6 us, 512 59.0, 1024 73.0, 2048 98.9.  At least one 32-row tile per wave of a workgroup.
-    static const int target = [] { const char* e = getenv("MPO_COATTN_TARGET_WGS"); return e ? atoi(e) : 256; }();
+    // uniform cut: the same number of row ranges for every slide; at least one 32-row tile per wave of a workgroup
+    const int target = mpo_coattn_target_workgroups();
     int s = (target + n_slides - 1) / n_slides;
     if (s > 512) s = 512;
     const int cap = (max_rows + 127) / 128;
@@ -102,9 +113,33 @@ extern "C" int mpo_coattn_splits(int n_slides, int max_rows) {
     return s;
 }
 
+// C-ABI plan -> kernel plan.  NULL (or a NULL wg_start) selects the uniform cut.
+static BagPlan make_plan(const mpo_bag_plan* p, int n_slides, int max_rows) {
+    BagPlan pl;
+    pl.n_slides = n_slides;
+    if (p != nullptr && p->wg_start != nullptr) {
+        pl.wg_start = p->wg_start;
+        pl.n_wg = p->n_wg;
+        pl.rows_per_wg = p->rows_per_wg;
+    } else {
+        pl.splits = mpo_coattn_splits(n_slides, max_rows);
+    }
+    return pl;
+}
+static int check_plan(const BagPlan& pl, int n_slides) {
+    if (pl.wg_start == nullptr) return 0;
+    MPO_CHECK(pl.rows_per_wg >= kTileRows && pl.rows_per_wg % kTileRows == 0, "bag plan: rows_per_wg %d must be a positive multiple of %d",
+              pl.rows_per_wg, kTileRows);
+    MPO_CHECK(pl.n_wg >= n_slides && pl.n_wg <= mpo_coattn_target_workgroups() + n_slides,
+              "bag plan: n_wg %d outside [n_slides, target + n_slides]", pl.n_wg);
+    return 0;
+}
+// upper bound on the number of split-M partials of any plan for this window
+static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgroups() + (size_t)n_slides; }
+
 extern "C" {
 
-int mpo_abi_version(void) { return 1; }
+int mpo_abi_version(void) { return 2; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -129,16 +164,17 @@ size_t mpo_coattn_saved_floats(int n_slides, int n_q, int embed) {
 
 size_t mpo_coattn_workspace_bytes(int n_slides, int n_q, int embed, int max_rows) {
     const size_t R = (size_t)n_slides * n_q;
-    const size_t splits = mpo_coattn_splits(n_slides, max_rows);
+    const size_t parts = max_parts(n_slides);
+    (void)max_rows;
     size_t a = 0;
     // forward: part_ml, part_ctx.  backward: dattn, dctx, dqk, dq_pre, delta, part_dqk  (take the larger)
     size_t f = 0;
-    f = arena_need(f, (size_t)n_slides * splits * 32);
-    f = arena_need(f, (size_t)n_slides * splits * n_q * embed);
+    f = arena_need(f, parts * 32);
+    f = arena_need(f, parts * n_q * embed);
     size_t b = 0;
     for (int i = 0; i < 4; ++i) b = arena_need(b, R * embed);
     b = arena_need(b, R);
-    b = arena_need(b, (size_t)n_slides * splits * n_q * embed);
+    b = arena_need(b, parts * n_q * embed);
     a = f > b ? f : b;
     return a + 256;
 }
@@ -156,13 +192,15 @@ static int check_common(int bag_dtype, int n_slides, int total_rows, int max_row
 int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int total_rows,
                             int max_rows, const float* query, int n_q, int embed, const float* in_w,
                             const float* in_b, const float* out_w, const float* out_b, float* out, float* attn_map,
-                            float* saved, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+                            float* saved, const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes,
+                            mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     const int E = embed, R = n_slides * n_q;
-    const int splits = mpo_coattn_splits(n_slides, max_rows);
+    const BagPlan plan = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(plan, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
-    float* part_ml = ws.floats((size_t)n_slides * splits * 32);
-    float* part_ctx = ws.floats((size_t)n_slides * splits * n_q * E);
+    float* part_ml = ws.floats(plan_parts(plan) * 32);
+    float* part_ctx = ws.floats(plan_parts(plan) * n_q * E);
     MPO_CHECK(part_ml && part_ctx, "coattn forward: workspace too small (%zu bytes)", workspace_bytes);
     float* qs = saved;
     float* qk2 = qs + (size_t)R * E;
@@ -176,8 +214,8 @@ int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_ro
     // qk2 = log2(e) * qs W_k     (fold of the key projection into the query; key bias cancels in softmax)
     if ((rc = mpo_linear_bwd_input(qs, in_w + (size_t)E * E, qk2, R, E, E, kLog2e, 0, stream))) return rc;
     if ((rc = mpo_launch_coattn_fwd_partial(bag, bag_dtype == MPO_F32, cu_rows, n_slides, E, qk2, part_ml, part_ctx,
-                                            attn_map, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_coattn_combine(part_ml, part_ctx, ctx, lse2, n_slides, n_q, E, splits, stream))) return rc;
+                                            attn_map, n_q, plan, stream))) return rc;
+    if ((rc = mpo_launch_coattn_combine(part_ml, part_ctx, ctx, lse2, n_slides, n_q, E, plan, stream))) return rc;
     // attn = ctx W_v^T + b_v   (rows of A sum to one);  out = attn W_o^T + b_o
     if ((rc = mpo_linear_fwd(ctx, in_w + (size_t)2 * E * E, in_b + 2 * E, attn, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_linear_fwd(attn, out_w, out_b, out, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
@@ -190,20 +228,21 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                              int max_rows, const float* query, int n_q, int embed, const float* in_w,
                              const float* out_w, const float* saved, const float* attn_map, const float* d_out,
                              const float* d_attn_map, float* d_query, void* d_bag, float* d_in_w, float* d_in_b,
-                             float* d_out_w, float* d_out_b, float bag_relu_gate, void* workspace, size_t workspace_bytes,
-                             mpo_stream_t stream) {
+                             float* d_out_w, float* d_out_b, float bag_relu_gate, const mpo_bag_plan* plan_,
+                             void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "coattn backward: embed_dim 512 ('big') is not built yet");
     MPO_CHECK(!d_attn_map || attn_map, "coattn backward: a gradient on the attention map needs the forward's map");
     const int E = embed, R = n_slides * n_q;
-    const int splits = mpo_coattn_splits(n_slides, max_rows);
+    const BagPlan plan = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(plan, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
     float* dattn = ws.floats((size_t)R * E);
     float* dctx = ws.floats((size_t)R * E);
     float* dqk = ws.floats((size_t)R * E);
     float* dq_pre = ws.floats((size_t)R * E);
     float* delta = ws.floats(R);
-    float* part_dqk = ws.floats((size_t)n_slides * splits * n_q * E);
+    float* part_dqk = ws.floats(plan_parts(plan) * n_q * E);
     MPO_CHECK(dattn && dctx && dqk && dq_pre && delta && part_dqk, "coattn backward: workspace too small (%zu bytes)", workspace_bytes);
     const float* qs = saved;
     const float* qk2 = qs + (size_t)R * E;
@@ -227,8 +266,8 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
         if ((rc = mpo_launch_map_rowdot(attn_map, d_attn_map, cu_rows, delta, n_slides, n_q, 1, stream))) return rc;
     // the bag pass
     if ((rc = mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, E, qk2, lse2, dctx, delta, attn_map,
-                                    d_attn_map, d_bag, part_dqk, n_q, splits, bag_relu_gate, stream))) return rc;
-    if ((rc = mpo_launch_coattn_bwd_reduce(part_dqk, dqk, n_slides, n_q, E, splits, stream))) return rc;
+                                    d_attn_map, d_bag, part_dqk, n_q, plan, bag_relu_gate, stream))) return rc;
+    if ((rc = mpo_launch_coattn_bwd_reduce(part_dqk, dqk, n_slides, n_q, E, plan, stream))) return rc;
     // qk = qs W_k :  dqs = dqk W_k^T (folded with the 1/sqrt(E) of qs = scale * (...)),  dW_k = qs^T dqk,  db_k = 0
     if ((rc = mpo_linear_fwd(dqk, w_k, nullptr, dq_pre, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_linear_bwd_weight(qs, dqk, d_in_w + (size_t)E * E, nullptr, R, E, E, 1.0f, stream))) return rc;
@@ -247,11 +286,11 @@ size_t mpo_nacagat_saved_floats(int n_slides, int n_q, int embed) {
 }
 size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_rows, int total_rows) {
     const size_t R = (size_t)n_slides * n_q;
-    const size_t splits = mpo_coattn_splits(n_slides, max_rows);
+    (void)max_rows;
     size_t b = 0;
     for (int i = 0; i < 6; ++i) b = arena_need(b, R * embed);
     b = arena_need(b, R);
-    b = arena_need(b, (size_t)n_slides * splits * n_q * embed);
+    b = arena_need(b, max_parts(n_slides) * n_q * embed);
     b = arena_need(b, (size_t)n_q * total_rows);
     b = arena_need(b, (size_t)n_q * total_rows);
     return b + 256;
@@ -262,15 +301,17 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
                                const float* in_w, const float* in_b, const float* out_w, const float* out_b,
                                float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                void* tkbag, float* q_proj, float* out, float* attn_map, float* score_maps,
-                               float* saved, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+                               float* saved, const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes,
+                               mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
     MPO_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention dropout p must be in [0,1) (got %f)", (double)drop_p);
     MPO_CHECK(k_dtype == MPO_F32 || k_dtype == MPO_BF16, "k dtype %d is neither MPO_F32 nor MPO_BF16", k_dtype);
     const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32, kf32 = k_dtype == MPO_F32;
-    const int splits = mpo_coattn_splits(n_slides, max_rows);
+    const BagPlan splits = make_plan(plan_, n_slides, max_rows);          // (named `splits`: it replaces the old count)
+    if (int rc = check_plan(splits, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
-    float* part = ws.floats((size_t)n_slides * splits * n_q * E);
+    float* part = ws.floats(plan_parts(splits) * n_q * E);
     MPO_CHECK(part, "nacagat forward: workspace too small (%zu bytes)", workspace_bytes);
     float* qt = saved;
     float* qs2 = qt + (size_t)R * E;
@@ -307,12 +348,13 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
                                 float* d_query, void* d_kbag, void* d_tk_scratch, void* d_hbag,
                                 float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
-                                void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+                                const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
     MPO_CHECK(k_dtype == MPO_F32 || k_dtype == MPO_BF16, "k dtype %d is neither MPO_F32 nor MPO_BF16", k_dtype);
     const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32, kf32 = k_dtype == MPO_F32;
-    const int splits = mpo_coattn_splits(n_slides, max_rows);
+    const BagPlan splits = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(splits, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
     float* dattn = ws.floats((size_t)R * E);
     float* dctx = ws.floats((size_t)R * E);
@@ -321,7 +363,7 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
     float* dq = ws.floats((size_t)R * E);
     float* spare = ws.floats((size_t)R * E);
     float* dasum = ws.floats(R);
-    float* part = ws.floats((size_t)n_slides * splits * n_q * E);
+    float* part = ws.floats(plan_parts(splits) * n_q * E);
     float* ds1_map = ws.floats((size_t)n_q * total_rows);
     float* dg_map = ws.floats((size_t)n_q * total_rows);
     MPO_CHECK(dattn && dctx && dqt && dtq && dq && spare && dasum && part && ds1_map && dg_map,
@@ -372,17 +414,21 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
 }
 
 int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
-                           const float* qk2, float* part_ml, float* part_ctx, float* raw_logits, int n_q, int splits,
-                           mpo_stream_t stream) {
+                           const float* qk2, float* part_ml, float* part_ctx, float* raw_logits, int n_q, int max_rows,
+                           const mpo_bag_plan* plan_, mpo_stream_t stream) {
+    const BagPlan plan = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(plan, n_slides)) return rc;
     return mpo_launch_coattn_fwd_partial(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, part_ml, part_ctx,
-                                         raw_logits, n_q, splits, stream);
+                                         raw_logits, n_q, plan, stream);
 }
 int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
                            const float* qk2, const float* lse2, const float* dctx, const float* delta,
-                           const float* d_attn_map, void* d_bag, float* part_dqk, int n_q, int splits,
-                           mpo_stream_t stream) {
+                           const float* d_attn_map, void* d_bag, float* part_dqk, int n_q, int max_rows,
+                           const mpo_bag_plan* plan_, mpo_stream_t stream) {
+    const BagPlan plan = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(plan, n_slides)) return rc;
     return mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, lse2, dctx, delta, nullptr,
-                                 d_attn_map, d_bag, part_dqk, n_q, splits, 0.f, stream);
+                                 d_attn_map, d_bag, part_dqk, n_q, plan, 0.f, stream);
 }
 
 // ------------------------------------------------------------------------------------------- patch layer epilogue

@@ -60,7 +60,7 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                        const float* __restrict__ da_map,   // nullable, ragged [n_q][M_b] per slide
                        void* __restrict__ dbag_,           // [total_rows][E], bag dtype
                        float* __restrict__ part_dqk,       // [n_slides][splits][n_q][E] (natural units)
-                       int n_q, int splits,
+                       int n_q, BagPlan plan,
                        float relu_gate /* 0: off; else 1/(1-p): dH *= (H > 0 ? relu_gate : 0), bf16 bag only */) {
     using G = TileGeom<E_>;
     using C = BwdCfg<E_, F32BAG>;
@@ -71,12 +71,8 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int split = blockIdx.x, b = blockIdx.y;
-    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
-    const int rps = ((m_rows + splits - 1) / splits + kTileRows - 1) / kTileRows * kTileRows;
-    const int r0 = split * rps;
-    const int r1 = min(m_rows, r0 + rps);
-    const int ntiles = r1 > r0 ? (r1 - r0 + kTileRows - 1) / kTileRows : 0;
+    const WgGeom wg = wg_geom(cu, plan);
+    const int b = wg.b, row_begin = wg.row_begin, m_rows = wg.m_rows, r0 = wg.r0, r1 = wg.r1, ntiles = wg.ntiles;
     const int n_my = wave < ntiles ? (ntiles - wave + WAVES - 1) / WAVES : 0;
 
     char* thi = lds + wave * C::WAVE_LDS;
@@ -254,7 +250,7 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
             *reinterpret_cast<f32x4*>(wq + c16 * E_ + 16 * t + 4 * g) = accq[t];
     }
     __syncthreads();
-    const size_t pbase = (size_t)b * splits + split;
+    const size_t pbase = wg.part;
     for (int idx = threadIdx.x; idx < n_q * E_; idx += WAVES * 64) {
         float a = 0.f;
 #pragma unroll
@@ -265,14 +261,16 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 
 // dqk[b][i] = sum_s part[b][s][i]: 64 float4 columns per workgroup, the 4 waves split the splits
 __global__ __launch_bounds__(256)
-void coattn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int per_slide, int splits) {
+void coattn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int per_slide, BagPlan plan) {
     __shared__ __attribute__((aligned(16))) float red[4][256];
     const int b = blockIdx.y, c = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i4 = blockIdx.x * 64 + c;                       // float4 index inside the slide's block
+    int s0, s1;
+    slide_parts(plan, b, s0, s1);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (4 * i4 < per_slide)
-        for (int s = w; s < splits; s += 4)
-            a += *reinterpret_cast<const f32x4*>(part + ((size_t)b * splits + s) * per_slide + 4 * i4);
+        for (int s = s0 + w; s < s1; s += 4)
+            a += *reinterpret_cast<const f32x4*>(part + (size_t)s * per_slide + 4 * i4);
     *reinterpret_cast<f32x4*>(&red[w][4 * c]) = a;
     __syncthreads();
     if (w == 0 && 4 * i4 < per_slide) {
@@ -318,18 +316,19 @@ __global__ void map_rowdot_kernel(const float* __restrict__ a_map, const float* 
 int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                           const float* qk2, const float* lse2, const float* dctx, const float* delta,
                           const float* a_map, const float* da_map,
-                          void* dbag, float* part_dqk, int n_q, int splits, float relu_gate, hipStream_t stream) {
+                          void* dbag, float* part_dqk, int n_q, const BagPlan& plan, float relu_gate, hipStream_t stream) {
+    (void)n_slides;
     (void)a_map;
     MPO_CHECK(relu_gate == 0.f || !bag_f32, "coattn backward: the fused relu/dropout gate needs a bf16 bag");
-    dim3 grid(splits, n_slides);
+    dim3 grid = plan_grid(plan);
 #define MPO_BWD_CASE(EV)                                                                                     \
     case EV:                                                                                                 \
         if (bag_f32)                                                                                         \
             coattn_bwd_kernel<EV, true><<<grid, BwdCfg<EV, true>::WAVES * 64, 0, stream>>>(                  \
-                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, splits, relu_gate);           \
+                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, plan, relu_gate);           \
         else                                                                                                 \
             coattn_bwd_kernel<EV, false><<<grid, BwdCfg<EV, false>::WAVES * 64, 0, stream>>>(                \
-                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, splits, relu_gate);           \
+                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, plan, relu_gate);           \
         break;
     switch (embed) {
         MPO_BWD_CASE(128)
@@ -343,11 +342,11 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
     return 0;
 }
 
-int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, int splits,
+int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, const BagPlan& plan,
                                  hipStream_t stream) {
     const int per = n_q * embed;
     dim3 grid((per / 4 + 63) / 64, n_slides);
-    coattn_bwd_reduce_kernel<<<grid, 256, 0, stream>>>(part_dqk, dqk, per, splits);
+    coattn_bwd_reduce_kernel<<<grid, 256, 0, stream>>>(part_dqk, dqk, per, plan);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -83,7 +83,7 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
                                float* __restrict__ part_ml,       // [n_slides][splits][16][2]
                                float* __restrict__ part_ctx,      // [n_slides][splits][n_q][E]
                                float* __restrict__ s_out,         // nullable; slide b at n_q*cu[b], [n_q][M_b]
-                               int n_q, int splits) {
+                               int n_q, BagPlan plan) {
     using G = TileGeom<E_>;
     using C = FwdCfg<E_, F32BAG>;
     constexpr int WAVES = C::WAVES;
@@ -91,12 +91,8 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: uniform control flow
-    const int split = blockIdx.x, b = blockIdx.y;
-    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
-    const int rps = ((m_rows + splits - 1) / splits + kTileRows - 1) / kTileRows * kTileRows;
-    const int r0 = split * rps;
-    const int r1 = min(m_rows, r0 + rps);
-    const int ntiles = r1 > r0 ? (r1 - r0 + kTileRows - 1) / kTileRows : 0;
+    const WgGeom wg = wg_geom(cu, plan);
+    const int b = wg.b, row_begin = wg.row_begin, m_rows = wg.m_rows, r0 = wg.r0, r1 = wg.r1, ntiles = wg.ntiles;
     const int n_my = wave < ntiles ? (ntiles - wave + WAVES - 1) / WAVES : 0;
 
     char* thi = lds + wave * C::WAVE_LDS;
@@ -181,7 +177,7 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
     }
     __syncthreads();
     const float* ml = reinterpret_cast<const float*>(lds + C::ML_OFF);
-    const size_t pbase = (size_t)b * splits + split;
+    const size_t pbase = wg.part;
     for (int idx = threadIdx.x; idx < n_q * E_; idx += WAVES * 64) {
         const int qq = idx / E_;
         float mt = -INFINITY;
@@ -217,14 +213,17 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
 template <int E_>
 __global__ __launch_bounds__(256)
 void coattn_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_ctx,
-                           float* __restrict__ ctx, float* __restrict__ lse2, int n_q, int splits) {
+                           float* __restrict__ ctx, float* __restrict__ lse2, int n_q, BagPlan plan) {
     constexpr int DG = E_ / 4;                 // float4 columns
     constexpr int NSG = 256 / DG;              // split groups (E=256: 4)
     __shared__ float wts[1024];
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) float accs[NSG][E_];
     const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const size_t p0 = (size_t)b * splits;
+    int s0, s1;
+    slide_parts(plan, b, s0, s1);
+    const size_t p0 = (size_t)s0;
+    const int splits = s1 - s0;
     float mt = -INFINITY;
     for (int s = tid; s < splits; s += 256) mt = fmaxf(mt, part_ml[(p0 + s) * 32 + 2 * q]);
     mt = wave_max(mt);
@@ -280,16 +279,17 @@ __global__ void coattn_normalize_kernel(float* __restrict__ a, const float* __re
 // ---------------------------------------------------------------------------- host launchers
 int mpo_launch_coattn_fwd_partial(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                                   const float* qk2, float* part_ml, float* part_ctx, float* s_out,
-                                  int n_q, int splits, hipStream_t stream) {
-    dim3 grid(splits, n_slides);
+                                  int n_q, const BagPlan& plan, hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
 #define MPO_FWD_CASE(EV)                                                                                   \
     case EV:                                                                                               \
         if (bag_f32)                                                                                       \
             coattn_fwd_partial_kernel<EV, true><<<grid, FwdCfg<EV, true>::WAVES * 64, 0, stream>>>(        \
-                bag, cu, qk2, part_ml, part_ctx, s_out, n_q, splits);                                      \
+                bag, cu, qk2, part_ml, part_ctx, s_out, n_q, plan);                                      \
         else                                                                                               \
             coattn_fwd_partial_kernel<EV, false><<<grid, FwdCfg<EV, false>::WAVES * 64, 0, stream>>>(      \
-                bag, cu, qk2, part_ml, part_ctx, s_out, n_q, splits);                                      \
+                bag, cu, qk2, part_ml, part_ctx, s_out, n_q, plan);                                      \
         break;
     switch (embed) {
         MPO_FWD_CASE(128)
@@ -305,13 +305,13 @@ int mpo_launch_coattn_fwd_partial(const void* bag, int bag_f32, const int* cu, i
 }
 
 int mpo_launch_coattn_combine(const float* part_ml, const float* part_ctx, float* ctx, float* lse2,
-                              int n_slides, int n_q, int embed, int splits, hipStream_t stream) {
-    MPO_CHECK(splits <= 1024, "coattn combine: splits %d > 1024", splits);
+                              int n_slides, int n_q, int embed, const BagPlan& plan, hipStream_t stream) {
+    MPO_CHECK((plan.wg_start ? plan.n_wg : plan.splits) <= 1024 + n_slides, "coattn combine: too many partials per slide");
     dim3 grid(n_q, n_slides);
     switch (embed) {
-        case 128: coattn_combine_kernel<128><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, splits); break;
-        case 256: coattn_combine_kernel<256><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, splits); break;
-        case 512: coattn_combine_kernel<512><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, splits); break;
+        case 128: coattn_combine_kernel<128><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, plan); break;
+        case 256: coattn_combine_kernel<256><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, plan); break;
+        case 512: coattn_combine_kernel<512><<<grid, 256, 0, stream>>>(part_ml, part_ctx, ctx, lse2, n_q, plan); break;
         default: mpo_set_error("coattn: embed_dim %d not in {128,256,512}", embed); return 1;
     }
     MPO_LAUNCH_CHECK();

@@ -26,6 +26,61 @@
 
 constexpr int kTileRows = 32;
 
+// ---------------------------------------------------------------- work plan of a bag pass over a ragged window
+// A bag pass gives every workgroup one contiguous row range of one slide.
+//   uniform (wg_start == nullptr): grid (splits, n_slides); slide b is cut into `splits` equal ranges.
+//   planned (wg_start != nullptr): grid (n_wg); every workgroup gets `rows_per_wg` rows (multiple of 32), slide b owns
+//     workgroups wg_start[b] .. wg_start[b+1]-1, i.e. ceil(M_b / rows_per_wg) of them: splits proportional to the
+//     bag length, so a window of 2k..30k-patch bags is balanced (the uniform cut makes the longest slide set the time).
+// Partials are indexed by workgroup: b * splits + split (uniform) or the workgroup id (planned).
+struct BagPlan {
+    const int* wg_start = nullptr;   // device, n_slides + 1 entries
+    int n_slides = 0;
+    int splits = 1;
+    int rows_per_wg = 0;
+    int n_wg = 0;
+};
+inline dim3 plan_grid(const BagPlan& p) { return p.wg_start ? dim3(p.n_wg, 1) : dim3(p.splits, p.n_slides); }
+inline size_t plan_parts(const BagPlan& p) { return p.wg_start ? (size_t)p.n_wg : (size_t)p.splits * p.n_slides; }
+
+struct WgGeom {
+    int b, row_begin, m_rows, r0, r1, ntiles;
+    size_t part;                      // index of this workgroup's partial
+};
+__device__ __forceinline__ WgGeom wg_geom(const int* __restrict__ cu, const BagPlan& pl) {
+    WgGeom g;
+    int split, rps;
+    if (pl.wg_start != nullptr) {
+        const int wg = blockIdx.x;
+        int lo = 0, hi = pl.n_slides;                       // wg_start[lo] <= wg < wg_start[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pl.wg_start[mid] <= wg) lo = mid; else hi = mid;
+        }
+        g.b = lo;
+        split = wg - pl.wg_start[lo];
+        rps = pl.rows_per_wg;
+        g.part = wg;
+    } else {
+        g.b = blockIdx.y;
+        split = blockIdx.x;
+        rps = 0;
+        g.part = (size_t)g.b * pl.splits + split;
+    }
+    g.row_begin = cu[g.b];
+    g.m_rows = cu[g.b + 1] - g.row_begin;
+    if (pl.wg_start == nullptr) rps = ((g.m_rows + pl.splits - 1) / pl.splits + kTileRows - 1) / kTileRows * kTileRows;
+    g.r0 = split * rps;
+    g.r1 = min(g.m_rows, g.r0 + rps);
+    g.ntiles = g.r1 > g.r0 ? (g.r1 - g.r0 + kTileRows - 1) / kTileRows : 0;
+    return g;
+}
+// partial index range [s0, s1) of slide b
+__device__ __forceinline__ void slide_parts(const BagPlan& pl, int b, int& s0, int& s1) {
+    if (pl.wg_start != nullptr) { s0 = pl.wg_start[b]; s1 = pl.wg_start[b + 1]; }
+    else { s0 = b * pl.splits; s1 = s0 + pl.splits; }
+}
+
 template <int E_>
 struct TileGeom {
     static constexpr int ROWB = E_ * 2;                 // bytes per image row

@@ -102,19 +102,20 @@ inline int mpo_linear_bwd_weight(const float* dy, const float* x, float* dw, flo
 }
 
 // ---- K1/K2 long-bag cross-attention (coattn_fwd.hip / coattn_bwd.hip)
+struct BagPlan;
 extern "C" int mpo_coattn_splits(int n_slides, int max_rows);
 int mpo_launch_coattn_fwd_partial(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                                   const float* qk2, float* part_ml, float* part_ctx, float* s_out,
-                                  int n_q, int splits, hipStream_t stream);
+                                  int n_q, const BagPlan& plan, hipStream_t stream);
 int mpo_launch_coattn_combine(const float* part_ml, const float* part_ctx, float* ctx, float* lse2,
-                              int n_slides, int n_q, int embed, int splits, hipStream_t stream);
+                              int n_slides, int n_q, int embed, const BagPlan& plan, hipStream_t stream);
 int mpo_launch_coattn_normalize(float* a, const float* lse2, const int* cu, int n_slides, int n_q, int max_rows,
                                 float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream);
 int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                           const float* qk2, const float* lse2, const float* dctx, const float* delta,
                           const float* a_map, const float* da_map,
-                          void* dbag, float* part_dqk, int n_q, int splits, float relu_gate, hipStream_t stream);
-int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, int splits,
+                          void* dbag, float* part_dqk, int n_q, const BagPlan& plan, float relu_gate, hipStream_t stream);
+int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, const BagPlan& plan,
                                  hipStream_t stream);
 int mpo_launch_rowdot(const float* a, const float* b, float* out, int rows, int cols, hipStream_t stream);
 int mpo_launch_map_rowdot(const float* a_map, const float* da_map, const int* cu, float* delta, int n_slides, int n_q,
@@ -122,11 +123,11 @@ int mpo_launch_map_rowdot(const float* a_map, const float* da_map, const int* cu
 
 // ---- generic bag / map kernels (bagops.hip): the modular form of K2
 int mpo_launch_bag_rowdot(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* r,
-                          float* map, float alpha, int n_q, int splits, hipStream_t stream);
+                          float* map, float alpha, int n_q, const BagPlan& plan, hipStream_t stream);
 int mpo_launch_bag_colacc(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* wmap,
-                          float* part, int n_q, int splits, hipStream_t stream);
+                          float* part, int n_q, const BagPlan& plan, hipStream_t stream);
 int mpo_launch_bag_outer(const int* cu, int n_slides, int embed, const float* w1, const float* z1, const float* w2,
-                         const float* z2, void* dx, int out_f32, int n_q, int splits, hipStream_t stream);
+                         const float* z2, void* dx, int out_f32, int n_q, const BagPlan& plan, hipStream_t stream);
 int mpo_launch_gated_softmax_fwd(const float* amap_a, const float* gmap, const int* cu, float* out_map, float* lse2,
                                  float* asum, int n_slides, int n_q, float drop_p, unsigned long long seed,
                                  unsigned long long offset, const unsigned long long* epoch, hipStream_t stream);

@@ -25,6 +25,23 @@ class BagBatch:
     data: torch.Tensor
     cu: torch.Tensor
     lengths: List[int]
+    _plan: object = None
+
+    def plan(self):
+        """Work plan of the bag passes (mpo_bag_plan): rows per workgroup uniform over the whole window, so every
+        slide gets row ranges in proportion to its length.  Built once per window (one small H2D copy), kept alive
+        with the batch; returns a ctypes pointer for the C ABI."""
+        if self._plan is None:
+            target = L.lib().mpo_coattn_target_workgroups()
+            rpw = -(-self.total_rows // target)
+            rpw = max(32, -(-rpw // 32) * 32)
+            starts = [0]
+            for m in self.lengths:
+                starts.append(starts[-1] + -(-m // rpw))
+            wg = torch.tensor(starts, dtype=torch.int32).to(self.data.device, non_blocking=True)
+            c = L.BagPlanC(L.ptr(wg), starts[-1], rpw)
+            self._plan = (wg, c)
+        return ctypes.byref(self._plan[1])
 
     @property
     def n_slides(self):
@@ -46,7 +63,7 @@ class BagBatch:
 
     def with_data(self, data: torch.Tensor) -> "BagBatch":
         assert data.shape[0] == self.total_rows
-        return BagBatch(data, self.cu, self.lengths)
+        return BagBatch(data, self.cu, self.lengths, self._plan)
 
     def split_map(self, flat_map: torch.Tensor, n_q: int) -> "List[torch.Tensor]":
         """Ragged attention map -> list of (n_q, M_b) views (slide b starts at n_q * cu[b])."""
@@ -209,7 +226,7 @@ class CoAttnMCATFn(torch.autograd.Function):
         L.check(lib.mpo_coattn_mcat_forward(
             L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, batch.total_rows, batch.max_rows,
             L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), L.ptr(out_b),
-            L.ptr(out), L.ptr(amap), L.ptr(saved), L.ptr(ws), ws.numel(), L.stream_of(query)),
+            L.ptr(out), L.ptr(amap), L.ptr(saved), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)),
             "mpo_coattn_mcat_forward")
         ctx.save_for_backward(query, bag_data, in_w, out_w, saved, amap)
         ctx.param_refs = (in_w, in_b, out_w, out_b)
@@ -235,7 +252,7 @@ class CoAttnMCATFn(torch.autograd.Function):
             L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, batch.total_rows,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(out_w), L.ptr(saved), L.ptr(amap),
             L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), L.ptr(d_bag), L.ptr(d_in_w), L.ptr(d_in_b),
-            L.ptr(d_out_w), L.ptr(d_out_b), ctx.bag_relu_gate, L.ptr(ws), ws.numel(), L.stream_of(query)),
+            L.ptr(d_out_w), L.ptr(d_out_b), ctx.bag_relu_gate, batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)),
             "mpo_coattn_mcat_backward")
         return d_query, d_bag, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None
 
@@ -630,7 +647,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
             L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, T, batch.max_rows,
             L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), L.ptr(out_b), float(drop_p), seed, offset,
             _epoch(), L.ptr(tkbag), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
-            L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_forward")
+            batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_forward")
         ctx.save_for_backward(query, bag_data, kbag, tkbag, in_w, in_b, out_w, saved, score_maps, amap)
         ctx.param_refs = (in_w, in_b, out_w, out_b)
         ctx.batch, ctx.n_q, ctx.drop = batch, n_q, (float(drop_p), seed, offset)
@@ -658,7 +675,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
             _epoch(), L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
             L.ptr(d_query), L.ptr(d_k), L.ptr(d_tk), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
-            L.ptr(d_out_b), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
+            L.ptr(d_out_b), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
         # back through the caller-side GEMM  K = H W_k^T + b_k.  The forward K stays fp32 (the gate amplifies its
         # rounding); its GRADIENT goes through bf16 operands with fp32 accumulation for a bf16 bag: dW_k as a
         # batched split-K product (one 480 000-deep fp32 contraction took 1.19 ms in rocBLAS), dH += dK W_k as a

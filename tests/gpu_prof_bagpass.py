@@ -15,7 +15,7 @@ dbag = torch.empty_like(bags[0])
 qk2 = torch.randn(B * n_q, E, device=dev) * 0.05
 dctx = torch.randn(B * n_q, E, device=dev) * 0.05
 lib = L.lib()
-splits = lib.mpo_coattn_splits(B, M)
+splits = lib.mpo_coattn_target_workgroups() // B + 1
 part_ml = torch.empty(B * splits * 32, device=dev)
 part_ctx = torch.empty(B * splits * n_q * E, device=dev)
 lse2 = torch.full((B * n_q,), 14.0, device=dev)
@@ -23,7 +23,7 @@ delta = torch.zeros(B * n_q, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 for i in range(10):
     L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), 1, L.ptr(cu), B, E, L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx),
-                                       None, n_q, splits, s), "fwd")
+                                       None, n_q, M, None, s), "fwd")
     L.check(lib.mpo_coattn_bwd_bagpass(L.ptr(bags[i & 1]), 1, L.ptr(cu), B, E, L.ptr(qk2), L.ptr(lse2), L.ptr(dctx),
-                                       L.ptr(delta), None, L.ptr(dbag), L.ptr(part_ctx), n_q, splits, s), "bwd")
+                                       L.ptr(delta), None, L.ptr(dbag), L.ptr(part_ctx), n_q, M, None, s), "bwd")
 torch.cuda.synchronize()

@@ -17,13 +17,13 @@ def run(B, M, dt, reps=20):
     dbag = torch.empty_like(bags[0])
     qk2 = torch.randn(B * n_q, E, device=dev) * 0.05
     dctx = torch.randn(B * n_q, E, device=dev) * 0.05
-    splits = lib.mpo_coattn_splits(B, M)
+    splits = lib.mpo_coattn_target_workgroups() // B + 1
     part_ml = torch.empty(B * splits * 32, device=dev); part_ctx = torch.empty(B * splits * n_q * E, device=dev)
     lse2 = torch.full((B * n_q,), 14.0, device=dev); delta = torch.zeros(B * n_q, device=dev)
     st = torch.cuda.current_stream()
     code = L.bag_dtype_code(bags[0])
-    def fwd(i): L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), code, L.ptr(cu), B, E, L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, splits, st.cuda_stream), "f")
-    def bwd(i): L.check(lib.mpo_coattn_bwd_bagpass(L.ptr(bags[i & 1]), code, L.ptr(cu), B, E, L.ptr(qk2), L.ptr(lse2), L.ptr(dctx), L.ptr(delta), None, L.ptr(dbag), L.ptr(part_ctx), n_q, splits, st.cuda_stream), "b")
+    def fwd(i): L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), code, L.ptr(cu), B, E, L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, M, None, st.cuda_stream), "f")
+    def bwd(i): L.check(lib.mpo_coattn_bwd_bagpass(L.ptr(bags[i & 1]), code, L.ptr(cu), B, E, L.ptr(qk2), L.ptr(lse2), L.ptr(dctx), L.ptr(delta), None, L.ptr(dbag), L.ptr(part_ctx), n_q, M, None, st.cuda_stream), "b")
     out = []
     for fn, mult in ((fwd, 1), (bwd, 2)):
         for i in range(3): fn(i)
