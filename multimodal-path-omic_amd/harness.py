@@ -90,6 +90,7 @@ class GraphedWindowStep:
         from . import ops
         self.model, self.bucket, self.opt = model, bucket, opt
         self.window, self.acc = window, grad_acc_step
+        window[0].plan()                      # the work plan's H2D copy must not happen inside the capture
         dev = bucket.flat.device
         if ops._rng_epoch_tensor is None:
             ops.set_rng_epoch(torch.zeros(1, dtype=torch.int64, device=dev))
