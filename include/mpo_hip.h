@@ -121,13 +121,13 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
  *   S = (q/sqrt(E)) k^T * (tanh(q) tanh(k)^T + 1)/2,  A = softmax(S),  A_drop = dropout(A, p) in training,
  *   out = (A_drop v) W_o^T + b_o,  returns (q, out, A_drop)  -- the map is post-dropout, as in the reference.
  * The caller supplies kbag = H W_k^T + b_k (a plain GEMM it owns, like self.H; dtype k_dtype) and hbag = H;
- * the value projection is folded out.  tkbag (out, k_dtype) receives tanh(kbag) and is kept for backward.
- * k_dtype should be MPO_F32 even for a bf16 bag: the gate multiplies rounding errors of k (dS = (g+1) da),
+ * the value projection is folded out.  tanh(kbag) is recomputed on the fly in every pass, never stored.
+ * k_dtype must be MPO_F32 even for a bf16 bag: the gate multiplies rounding errors of k (dS = (g+1) da),
  * so k is an intermediate that must not be stored in bf16 (hard part 4).
  *   score_maps  2 * n_q * total_rows floats (kept for backward);  attn_map  n_q * total_rows floats (output)
  *   seed/offset Philox counter of the attention-weight dropout; pass the same pair to backward.
  * Backward takes gradients on all three returns (d_out, d_attn_map nullable, d_q_proj nullable) and emits
- * d_query, d_kbag (k_dtype; d_tk_scratch is scratch of the same size), d_hbag (bag dtype) and the q / v / out-projection
+ * d_query, d_kbag (dk_dtype: a GRADIENT may be handed on in bf16), d_hbag (bag dtype) and the q / v / out-projection
  * gradients; the key slices of d_in_proj_* are zeroed (the caller back-propagates d_kbag through its GEMM). */
 size_t mpo_nacagat_saved_floats(int n_slides, int n_q, int embed);
 size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_rows, int total_rows);
@@ -136,17 +136,17 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
                                const float* in_proj_weight, const float* in_proj_bias,
                                const float* out_proj_weight, const float* out_proj_bias,
                                float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
-                               void* tkbag, float* q_proj, float* out, float* attn_map, float* score_maps,
+                               float* q_proj, float* out, float* attn_map, float* score_maps,
                                float* saved, const mpo_bag_plan* plan /* nullable */,
                                void* workspace, size_t workspace_bytes, mpo_stream_t stream);
-int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype, const void* hbag, int bag_dtype,
+int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype,
                                 const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
                                 const float* query, int n_q, int embed,
                                 const float* in_proj_weight, const float* in_proj_bias, const float* out_proj_weight,
                                 float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
-                                float* d_query, void* d_kbag, void* d_tk_scratch, void* d_hbag,
+                                float* d_query, void* d_kbag, int dk_dtype, void* d_hbag,
                                 float* d_in_proj_weight, float* d_in_proj_bias,
                                 float* d_out_proj_weight, float* d_out_proj_bias, const mpo_bag_plan* plan /* nullable */,
                                 void* workspace, size_t workspace_bytes, mpo_stream_t stream);

@@ -233,6 +233,291 @@ void bag_outer_kernel(const int* __restrict__ cu, const float* __restrict__ w1, 
     }
 }
 
+// ------------------------------------------------------------------ gated (tanh on the fly) variants for K2
+// tanh(x) = 1 - 2 / (2^(2x log2 e) + 1): two transcendentals, saturates cleanly, abs error ~1e-7.
+__device__ __forceinline__ float fast_tanh(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * (2.0f * kLog2e));
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+// fragment of tanh(X) from the hi (+lo) images, split again into bf16 hi/lo
+template <int NT>
+__device__ __forceinline__ void tanh_frag(bf16x8 xh, bf16x8 xl, bf16x8& th, bf16x8& tl) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = fast_tanh(NT == 2 ? (float)xh[j] + (float)xl[j] : (float)xh[j]);
+    pack_hi_lo(t, th, tl);
+}
+
+// (i') ONE pass over K:  a_map[n][m] = K[m] . r1[n]   and   g_map[n][m] = tanh(K[m]) . r2[n]
+template <int E_, bool F32BAG>
+__global__ __launch_bounds__((BagCfg<E_, F32BAG>::WAVES * 64), 1)
+void bag_rowdot_gated_kernel(const void* __restrict__ bag_, const int* __restrict__ cu, const float* __restrict__ r1,
+                             const float* __restrict__ r2, float* __restrict__ a_map, float* __restrict__ g_map,
+                             int n_q, BagPlan plan) {
+    using G = TileGeom<E_>;
+    using C = BagCfg<E_, F32BAG>;
+    constexpr int NT = C::NT;
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeom sg = split_geom<C::WAVES>(cu, plan, wave);
+    const int b = sg.b;
+    char* thi = lds + wave * C::WAVE_LDS;
+    char* tlo = thi + (NT - 1) * G::TILEB;
+    const int q = lane & 15, g = lane >> 4;
+    bf16x8 ah[G::KS], al[G::KS], gh[G::KS], gl[G::KS];
+    load_query_frags<E_>(r1 + (size_t)b * n_q * E_, n_q, lane, ah, al);
+    load_query_frags<E_>(r2 + (size_t)b * n_q * E_, n_q, lane, gh, gl);
+    const size_t mbase = (size_t)n_q * sg.row_begin + (size_t)q * sg.m_rows;
+    const char* slide = reinterpret_cast<const char*>(bag_) + (size_t)sg.row_begin * E_ * (F32BAG ? 4 : 2);
+    Stage<E_, F32BAG> st0, st1;
+    if (sg.n_my > 0) {
+        st0.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 0, lane);
+        if constexpr (F32BAG) st1.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 1, lane);
+    }
+    for (int it = 0; it < sg.n_my; ++it) {
+        const int trow = sg.r0 + kTileRows * (wave + it * C::WAVES);
+        const int nvalid = min(kTileRows, sg.r1 - trow);
+        st0.store(thi, tlo, 0, lane);
+        if constexpr (F32BAG) st1.store(thi, tlo, 1, lane);
+        if (it + 1 < sg.n_my) {
+            st0.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 0, lane);
+            if constexpr (F32BAG) st1.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 1, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, g0 = a0, g1 = a0;
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const bf16x8 xh = row_frag<E_>(thi, pt, s, lane);
+                const bf16x8 xl = NT == 2 ? row_frag<E_>(tlo, pt, s, lane) : xh;
+                f32x4& a = pt == 0 ? a0 : a1;
+                f32x4& gg = pt == 0 ? g0 : g1;
+                a = mfma_bf16(xh, ah[s], a);
+                a = mfma_bf16(xh, al[s], a);
+                if (NT == 2) a = mfma_bf16(xl, ah[s], a);
+                bf16x8 th, tl;
+                tanh_frag<NT>(xh, xl, th, tl);
+                gg = mfma_bf16(th, gh[s], gg);
+                gg = mfma_bf16(th, gl[s], gg);
+                gg = mfma_bf16(tl, gh[s], gg);
+            }
+        }
+        if (q < n_q) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if (4 * g + rr < nvalid) {
+                    a_map[mbase + trow + 4 * g + rr] = a0[rr];
+                    g_map[mbase + trow + 4 * g + rr] = g0[rr];
+                }
+                if (16 + 4 * g + rr < nvalid) {
+                    a_map[mbase + trow + 16 + 4 * g + rr] = a1[rr];
+                    g_map[mbase + trow + 16 + 4 * g + rr] = g1[rr];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// (ii') ONE pass over K:  part1[n][e] = sum_m W1[n][m] K[m][e]   and   part2[n][e] = sum_m W2[n][m] tanh(K[m][e])
+template <int E_, bool F32BAG>
+__global__ __launch_bounds__((BagCfg<E_, F32BAG>::WAVES * 64), 1)
+void bag_colacc_gated_kernel(const void* __restrict__ bag_, const int* __restrict__ cu, const float* __restrict__ w1map,
+                             const float* __restrict__ w2map, float* __restrict__ part1, float* __restrict__ part2,
+                             int n_q, BagPlan plan) {
+    using G = TileGeom<E_>;
+    using C = BagCfg<E_, F32BAG>;
+    constexpr int NT = C::NT;
+    __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeom sg = split_geom<C::WAVES>(cu, plan, wave);
+    char* thi = lds + wave * C::WAVE_LDS;
+    char* tlo = thi + (NT - 1) * G::TILEB;
+    const int q = lane & 15, g = lane >> 4;
+    const size_t mbase = (size_t)n_q * sg.row_begin + (size_t)(q < n_q ? q : 0) * sg.m_rows;
+    const char* slide = reinterpret_cast<const char*>(bag_) + (size_t)sg.row_begin * E_ * (F32BAG ? 4 : 2);
+    f32x4 acc1[G::DT], acc2[G::DT];
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) { acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = acc1[t]; }
+    Stage<E_, F32BAG> st0, st1;
+    if (sg.n_my > 0) {
+        st0.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 0, lane);
+        if constexpr (F32BAG) st1.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 1, lane);
+    }
+    for (int it = 0; it < sg.n_my; ++it) {
+        const int trow = sg.r0 + kTileRows * (wave + it * C::WAVES);
+        const int nvalid = min(kTileRows, sg.r1 - trow);
+        float w1[8], w2[8];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const bool ok0 = q < n_q && 4 * g + rr < nvalid, ok1 = q < n_q && 16 + 4 * g + rr < nvalid;
+            w1[rr] = ok0 ? w1map[mbase + trow + 4 * g + rr] : 0.f;
+            w2[rr] = ok0 ? w2map[mbase + trow + 4 * g + rr] : 0.f;
+            w1[4 + rr] = ok1 ? w1map[mbase + trow + 16 + 4 * g + rr] : 0.f;
+            w2[4 + rr] = ok1 ? w2map[mbase + trow + 16 + 4 * g + rr] : 0.f;
+        }
+        st0.store(thi, tlo, 0, lane);
+        if constexpr (F32BAG) st1.store(thi, tlo, 1, lane);
+        if (it + 1 < sg.n_my) {
+            st0.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 0, lane);
+            if constexpr (F32BAG) st1.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 1, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 w1h, w1l, w2h, w2l;
+        pack_hi_lo(w1, w1h, w1l);
+        pack_hi_lo(w2, w2h, w2l);
+#pragma unroll
+        for (int t = 0; t < G::DT; ++t) {
+            const bf16x8 xh = col_frag<E_>(thi, t, lane);
+            const bf16x8 xl = NT == 2 ? col_frag<E_>(tlo, t, lane) : xh;
+            acc1[t] = mfma_bf16(xh, w1h, acc1[t]);
+            acc1[t] = mfma_bf16(xh, w1l, acc1[t]);
+            if (NT == 2) acc1[t] = mfma_bf16(xl, w1h, acc1[t]);
+            bf16x8 th, tl;
+            tanh_frag<NT>(xh, xl, th, tl);
+            acc2[t] = mfma_bf16(th, w2h, acc2[t]);
+            acc2[t] = mfma_bf16(th, w2l, acc2[t]);
+            acc2[t] = mfma_bf16(tl, w2h, acc2[t]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const size_t pbase = sg.part;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        {
+            float* wq = reinterpret_cast<float*>(thi);
+#pragma unroll
+            for (int t = 0; t < G::DT; ++t)
+                *reinterpret_cast<f32x4*>(wq + q * E_ + 16 * t + 4 * g) = pass == 0 ? acc1[t] : acc2[t];
+        }
+        __syncthreads();
+        float* part = pass == 0 ? part1 : part2;
+        for (int idx = threadIdx.x; idx < n_q * E_; idx += C::WAVES * 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::WAVES; ++w) a += reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[idx];
+            part[pbase * n_q * E_ + idx] = a;
+        }
+    }
+}
+
+// (iii') dK[m][e] = sum_n W1[n][m] Z1[n][e] + (sum_n W2[n][m] Z2[n][e]) * (1 - tanh(K[m][e])^2),  K and dK fp32.
+// The K tile is staged (coalesced) into the fp32 image that then receives dK: each slot is read (K) right before it
+// is overwritten (dK), so tanh' costs no extra pass over the bag.
+template <int E_, bool OUT_BF16>
+__global__ __launch_bounds__(256, 1)
+void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restrict__ cu, const float* __restrict__ w1,
+                            const float* __restrict__ z1, const float* __restrict__ w2, const float* __restrict__ z2,
+                            void* __restrict__ dk, int n_q, BagPlan plan) {
+    using G = TileGeom<E_>;
+    constexpr int IMG = kTileRows * E_ * 4;
+    constexpr int CH_PER_ROW = E_ / 4;
+    constexpr int NCH = kTileRows * CH_PER_ROW / 64;         // float4 per lane per tile (32 for E = 256)
+    __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeom sg = split_geom<4>(cu, plan, wave);
+    const int b = sg.b;
+    char* img = lds + wave * IMG;
+    const int c16 = lane & 15, g = lane >> 4;
+    const float* z1b = z1 + (size_t)b * n_q * E_;
+    const float* z2b = z2 + (size_t)b * n_q * E_;
+    bf16x8 z1h[G::DT], z1l[G::DT], z2h[G::DT], z2l[G::DT];
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) {
+        float a[8], c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int qq = 4 * g + (j & 3);
+            const int qc = qq < n_q ? qq : n_q - 1;
+            const float live = (qq < n_q && j < 4) ? 1.0f : 0.0f;       // k-slots 4..7 unused (zero)
+            a[j] = z1b[qc * E_ + 16 * t + c16] * live;
+            c[j] = z2b[qc * E_ + 16 * t + c16] * live;
+        }
+        pack_hi_lo(a, z1h[t], z1l[t]);
+        pack_hi_lo(c, z2h[t], z2l[t]);
+    }
+    const float* w1b = w1 + (size_t)n_q * sg.row_begin;
+    const float* w2b = w2 + (size_t)n_q * sg.row_begin;
+    const float* kslide = kbag + (size_t)sg.row_begin * E_;
+    char* dslide = reinterpret_cast<char*>(dk) + (size_t)sg.row_begin * E_ * (OUT_BF16 ? 2 : 4);
+    for (int it = 0; it < sg.n_my; ++it) {
+        const int trow = sg.r0 + kTileRows * (wave + it * 4);
+        const int nvalid = min(kTileRows, sg.r1 - trow);
+        // stage K (fp32) into the image, same chunk swizzle as the output image
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = i * 64 + lane;
+            const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
+            int grow = trow + r;
+            grow = grow < sg.m_rows ? grow : sg.m_rows - 1;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(kslide + (size_t)grow * E_ + cc * 4);
+            *reinterpret_cast<f32x4*>(img + r * (E_ * 4) + ((cc ^ ((r & 7) << 1)) << 4)) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int row = 16 * pt + c16;
+            const bool ok = row < nvalid;
+            float wa[8], wb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int qq = 4 * g + (j & 3);
+                const bool live = ok && qq < n_q && j < 4;
+                wa[j] = live ? w1b[(size_t)qq * sg.m_rows + trow + row] : 0.f;
+                wb[j] = live ? w2b[(size_t)qq * sg.m_rows + trow + row] : 0.f;
+            }
+            bf16x8 wah, wal, wbh, wbl;
+            pack_hi_lo(wa, wah, wal);
+            pack_hi_lo(wb, wbh, wbl);
+#pragma unroll
+            for (int t = 0; t < G::DT; ++t) {
+                f32x4 o1 = {0.f, 0.f, 0.f, 0.f}, o2 = o1;
+                o1 = mfma_bf16(z1h[t], wah, o1);
+                o1 = mfma_bf16(z1h[t], wal, o1);
+                o1 = mfma_bf16(z1l[t], wah, o1);
+                o2 = mfma_bf16(z2h[t], wbh, o2);
+                o2 = mfma_bf16(z2h[t], wbl, o2);
+                o2 = mfma_bf16(z2l[t], wbh, o2);
+                const int c = (4 * t + g) ^ ((row & 7) << 1);
+                f32x4* slot = reinterpret_cast<f32x4*>(img + row * (E_ * 4) + (c << 4));
+                const f32x4 kv = *slot;
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float tk = fast_tanh(kv[j]);
+                    o[j] = o1[j] + o2[j] * (1.0f - tk * tk);
+                }
+                *slot = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = i * 64 + lane;
+            const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(img + r * (E_ * 4) + ((cc ^ ((r & 7) << 1)) << 4));
+            if (r < nvalid) {
+                if constexpr (OUT_BF16) {
+                    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(dslide + ((size_t)(trow + r) * E_ + cc * 4) * 2) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(dslide + ((size_t)(trow + r) * E_ + cc * 4) * 4) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------ map kernels (one workgroup per (query, slide))
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
@@ -538,6 +823,47 @@ int mpo_launch_bag_outer(const int* cu, int n_slides, int embed, const float* w1
         MPO_E_SWITCH(embed, (bag_outer_kernel<EV, true><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, plan)))
     } else {
         MPO_E_SWITCH(embed, (bag_outer_kernel<EV, false><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, plan)))
+    }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_bag_rowdot_gated(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* r1,
+                                const float* r2, float* a_map, float* g_map, int n_q, const BagPlan& plan, hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
+    if (bag_f32) {
+        MPO_E_SWITCH(embed, (bag_rowdot_gated_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, r1, r2, a_map, g_map, n_q, plan)))
+    } else {
+        MPO_E_SWITCH(embed, (bag_rowdot_gated_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, r1, r2, a_map, g_map, n_q, plan)))
+    }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_bag_colacc_gated(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* w1map,
+                                const float* w2map, float* part1, float* part2, int n_q, const BagPlan& plan,
+                                hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
+    if (bag_f32) {
+        MPO_E_SWITCH(embed, (bag_colacc_gated_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, w1map, w2map, part1, part2, n_q, plan)))
+    } else {
+        MPO_E_SWITCH(embed, (bag_colacc_gated_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, w1map, w2map, part1, part2, n_q, plan)))
+    }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_bag_outer_gated(const float* kbag, const int* cu, int n_slides, int embed, const float* w1, const float* z1,
+                               const float* w2, const float* z2, void* dk, int dk_f32, int n_q, const BagPlan& plan,
+                               hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
+    if (dk_f32) {
+        MPO_E_SWITCH(embed, (bag_outer_gated_kernel<EV, false><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, n_q, plan)))
+    } else {
+        MPO_E_SWITCH(embed, (bag_outer_gated_kernel<EV, true><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, n_q, plan)))
     }
     MPO_LAUNCH_CHECK();
     return 0;

@@ -139,7 +139,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 2; }
+int mpo_abi_version(void) { return 3; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -291,6 +291,7 @@ size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_row
     for (int i = 0; i < 6; ++i) b = arena_need(b, R * embed);
     b = arena_need(b, R);
     b = arena_need(b, max_parts(n_slides) * n_q * embed);
+    b = arena_need(b, max_parts(n_slides) * n_q * embed);
     b = arena_need(b, (size_t)n_q * total_rows);
     b = arena_need(b, (size_t)n_q * total_rows);
     return b + 256;
@@ -300,14 +301,14 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
                                int total_rows, int max_rows, const float* query, int n_q, int embed,
                                const float* in_w, const float* in_b, const float* out_w, const float* out_b,
                                float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
-                               void* tkbag, float* q_proj, float* out, float* attn_map, float* score_maps,
+                               float* q_proj, float* out, float* attn_map, float* score_maps,
                                float* saved, const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes,
                                mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
     MPO_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention dropout p must be in [0,1) (got %f)", (double)drop_p);
-    MPO_CHECK(k_dtype == MPO_F32 || k_dtype == MPO_BF16, "k dtype %d is neither MPO_F32 nor MPO_BF16", k_dtype);
-    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32, kf32 = k_dtype == MPO_F32;
+    MPO_CHECK(k_dtype == MPO_F32, "nacagat co-attention: K must be fp32 (k_dtype %d): the narrow gate amplifies key rounding", k_dtype);
+    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32;
     const BagPlan splits = make_plan(plan_, n_slides, max_rows);          // (named `splits`: it replaces the old count)
     if (int rc = check_plan(splits, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
@@ -326,9 +327,8 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
     // q = query W_q^T + b_q  (returned: the reference hands it to the CAG, models/blocks.py:110,206)
     if ((rc = mpo_linear_fwd(query, in_w, in_b, q_proj, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_launch_qprep(q_proj, qt, qs2, tq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
-    if ((rc = mpo_launch_bag_tanh_fwd(kbag, tkbag, (size_t)total_rows * E, kf32, stream))) return rc;
-    if ((rc = mpo_launch_bag_rowdot(kbag, kf32, cu_rows, n_slides, E, qs2, a_map, 1.0f, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_bag_rowdot(tkbag, kf32, cu_rows, n_slides, E, tq, g_map, 1.0f, n_q, splits, stream))) return rc;
+    // one pass over K: a = qs2 . K and g = tanh(q) . tanh(K)   (tanh(K) is never materialised)
+    if ((rc = mpo_launch_bag_rowdot_gated(kbag, 1, cu_rows, n_slides, E, qs2, tq, a_map, g_map, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_gated_softmax_fwd(a_map, g_map, cu_rows, attn_map, lse2, asum, n_slides, n_q, drop_p, seed, offset,
                                            reinterpret_cast<const unsigned long long*>(rng_epoch), stream))) return rc;
     if ((rc = mpo_launch_bag_colacc(hbag, f32, cu_rows, n_slides, E, attn_map, part, n_q, splits, stream))) return rc;
@@ -340,19 +340,20 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
     return 0;
 }
 
-int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype, const void* hbag, int bag_dtype,
+int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype,
                                 const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
                                 const float* query, int n_q, int embed, const float* in_w, const float* in_b,
                                 const float* out_w, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
-                                float* d_query, void* d_kbag, void* d_tk_scratch, void* d_hbag,
+                                float* d_query, void* d_kbag, int dk_dtype, void* d_hbag,
                                 float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
                                 const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
-    MPO_CHECK(k_dtype == MPO_F32 || k_dtype == MPO_BF16, "k dtype %d is neither MPO_F32 nor MPO_BF16", k_dtype);
-    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32, kf32 = k_dtype == MPO_F32;
+    MPO_CHECK(k_dtype == MPO_F32, "nacagat co-attention: K must be fp32 (k_dtype %d): the narrow gate amplifies key rounding", k_dtype);
+    MPO_CHECK(dk_dtype == MPO_F32 || dk_dtype == MPO_BF16, "d_kbag dtype %d is neither MPO_F32 nor MPO_BF16", dk_dtype);
+    const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32;
     const BagPlan splits = make_plan(plan_, n_slides, max_rows);
     if (int rc = check_plan(splits, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
@@ -364,9 +365,10 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
     float* spare = ws.floats((size_t)R * E);
     float* dasum = ws.floats(R);
     float* part = ws.floats(plan_parts(splits) * n_q * E);
+    float* part2 = ws.floats(plan_parts(splits) * n_q * E);
     float* ds1_map = ws.floats((size_t)n_q * total_rows);
     float* dg_map = ws.floats((size_t)n_q * total_rows);
-    MPO_CHECK(dattn && dctx && dqt && dtq && dq && spare && dasum && part && ds1_map && dg_map,
+    MPO_CHECK(dattn && dctx && dqt && dtq && dq && spare && dasum && part && part2 && ds1_map && dg_map,
               "nacagat backward: workspace too small (%zu bytes)", workspace_bytes);
     const float* qt = saved;
     const float* qs2 = qt + (size_t)R * E;
@@ -395,17 +397,17 @@ int mpo_coattn_nacagat_backward(const void* kbag, const void* tkbag, int k_dtype
     if ((rc = mpo_launch_gated_softmax_bwd(a_map, g_map, cu_rows, lse2, dasum, d_attn_map, ds1_map, dg_map, n_slides, n_q,
                                            drop_p, seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), stream))) return rc;
     // query side: dq~ = ds1 K, dtq = dg TK
-    if ((rc = mpo_launch_bag_colacc(kbag, kf32, cu_rows, n_slides, E, ds1_map, part, n_q, splits, stream))) return rc;
+    // (one pass over K, tanh on the fly)
+    if ((rc = mpo_launch_bag_colacc_gated(kbag, 1, cu_rows, n_slides, E, ds1_map, dg_map, part, part2, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part, dqt, n_slides, n_q, E, splits, stream))) return rc;
-    if ((rc = mpo_launch_bag_colacc(tkbag, kf32, cu_rows, n_slides, E, dg_map, part, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_coattn_bwd_reduce(part, dtq, n_slides, n_q, E, splits, stream))) return rc;
+    if ((rc = mpo_launch_coattn_bwd_reduce(part2, dtq, n_slides, n_q, E, splits, stream))) return rc;
     if ((rc = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
     if ((rc = mpo_linear_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0, stream))) return rc;
     if ((rc = mpo_linear_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f, stream))) return rc;
     // bag side: dK = ds1^T q~ + (dg^T tq) * (1 - TK^2),  dH = A_drop^T dctx
-    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, ds1_map, qt, nullptr, nullptr, d_kbag, kf32, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, dg_map, tq, nullptr, nullptr, d_tk_scratch, kf32, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_bag_tanh_bwd(tkbag, d_tk_scratch, d_kbag, (size_t)total_rows * E, kf32, stream))) return rc;
+    // (one pass: tanh' from the staged K tile)
+    if ((rc = mpo_launch_bag_outer_gated(static_cast<const float*>(kbag), cu_rows, n_slides, E, ds1_map, qt, dg_map, tq,
+                                         d_kbag, dk_dtype == MPO_F32, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, attn_map, dctx, nullptr, nullptr, d_hbag, f32, n_q, splits, stream))) return rc;
     // the key slice of the packed in-projection belongs to the caller's K = H W_k^T + b_k
     MPO_HIP(hipMemsetAsync(d_in_w + (size_t)E * E, 0, (size_t)E * E * sizeof(float), stream));

@@ -192,3 +192,13 @@ struct SideFork {
     hipStream_t sync();                              // returns the stream to launch the side work on
     int join();
 };
+
+// gated (tanh on the fly) single-pass variants for K2 (bagops.hip)
+int mpo_launch_bag_rowdot_gated(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* r1,
+                                const float* r2, float* a_map, float* g_map, int n_q, const BagPlan& plan, hipStream_t stream);
+int mpo_launch_bag_colacc_gated(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* w1map,
+                                const float* w2map, float* part1, float* part2, int n_q, const BagPlan& plan,
+                                hipStream_t stream);
+int mpo_launch_bag_outer_gated(const float* kbag, const int* cu, int n_slides, int embed, const float* w1, const float* z1,
+                               const float* w2, const float* z2, void* dk, int dk_f32, int n_q, const BagPlan& plan,
+                               hipStream_t stream);

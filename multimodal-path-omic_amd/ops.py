@@ -635,7 +635,6 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         dev, T = query.device, batch.total_rows
         query = query.contiguous()
         kbag = F.linear(bag_data.float(), in_w[E:2 * E], in_b[E:2 * E])
-        tkbag = torch.empty_like(kbag)
         q_proj = torch.empty(R, E, device=dev, dtype=torch.float32)
         out = torch.empty(R, E, device=dev, dtype=torch.float32)
         amap = torch.empty(n_q * T, device=dev, dtype=torch.float32)
@@ -646,9 +645,9 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         L.check(lib.mpo_coattn_nacagat_forward(
             L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, T, batch.max_rows,
             L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), L.ptr(out_b), float(drop_p), seed, offset,
-            _epoch(), L.ptr(tkbag), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
+            _epoch(), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
             batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_forward")
-        ctx.save_for_backward(query, bag_data, kbag, tkbag, in_w, in_b, out_w, saved, score_maps, amap)
+        ctx.save_for_backward(query, bag_data, kbag, in_w, in_b, out_w, saved, score_maps, amap)
         ctx.param_refs = (in_w, in_b, out_w, out_b)
         ctx.batch, ctx.n_q, ctx.drop = batch, n_q, (float(drop_p), seed, offset)
         return q_proj, out, amap
@@ -656,7 +655,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_qproj, d_out, d_map):
         lib = L.lib()
-        query, bag_data, kbag, tkbag, in_w, in_b, out_w, saved, score_maps, amap = ctx.saved_tensors
+        query, bag_data, kbag, in_w, in_b, out_w, saved, score_maps, amap = ctx.saved_tensors
         batch, n_q = ctx.batch, ctx.n_q
         drop_p, seed, offset = ctx.drop
         R, E = query.shape
@@ -665,16 +664,15 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         d_qproj = d_qproj.contiguous() if d_qproj is not None else None
         d_map = d_map.contiguous() if d_map is not None else None
         d_query = torch.empty_like(query)
-        d_k = torch.empty_like(kbag)
-        d_tk = torch.empty_like(kbag)
+        d_k = torch.empty_like(kbag, dtype=bag_data.dtype)       # a bf16 bag takes its key gradient in bf16 (see below)
         d_h = torch.empty_like(bag_data)
         d_in_w, d_in_b, d_out_w, d_out_b = (grad_out(p) for p in ctx.param_refs)
         ws = _workspace(lib.mpo_nacagat_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows, T), dev)
         L.check(lib.mpo_coattn_nacagat_backward(
-            L.ptr(kbag), L.ptr(tkbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
+            L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
             _epoch(), L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
-            L.ptr(d_query), L.ptr(d_k), L.ptr(d_tk), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
+            L.ptr(d_query), L.ptr(d_k), L.bag_dtype_code(d_k), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
             L.ptr(d_out_b), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
         # back through the caller-side GEMM  K = H W_k^T + b_k.  The forward K stays fp32 (the gate amplifies its
         # rounding); its GRADIENT goes through bf16 operands with fp32 accumulation for a bf16 bag: dW_k as a
@@ -682,13 +680,13 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         # bf16 GEMM (0.59 ms in fp32).
         w_k = in_w[E:2 * E]
         if bag_data.dtype == torch.bfloat16:
-            dk16 = d_k.to(torch.bfloat16)
-            d_h = torch.addmm(d_h, dk16, w_k.to(torch.bfloat16))
-            _splitk_tn(dk16, bag_data, d_in_w[E:2 * E])
+            d_h = torch.addmm(d_h, d_k, w_k.to(torch.bfloat16))
+            _splitk_tn(d_k, bag_data, d_in_w[E:2 * E])
+            _colsum_two_stage(d_k, d_in_b[E:2 * E])
         else:
             d_h = torch.addmm(d_h, d_k, w_k)
             d_in_w[E:2 * E] = torch.mm(d_k.t(), bag_data)
-        d_in_b[E:2 * E] = d_k.sum(0)
+            d_in_b[E:2 * E] = d_k.sum(0)
         return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None
 
 
