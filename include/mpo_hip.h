@@ -204,6 +204,16 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
                              const float* d_y, float* d_hcat, float* const* grads, int phase,
                              void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
+/* ---- 'ces' survival loss = CrossEntropySurvivalLoss.forward, models/loss.py:5-28, for n_slides slides at once
+ * (the reference calls it per slide, models/mcat/main.py:52); per-slide losses, no reduction.  risk (nullable)
+ * receives -sum_j survs_j (models/mcat/main.py:56).  Backward takes the per-slide upstream gradient d_loss
+ * (n_slides floats), or ONE device float broadcast to all slides when d_loss_is_scalar (loss.sum()/grad_acc_step). */
+int mpo_ces_loss_forward(const float* hazards, const float* survs, const int64_t* label, const float* censorship,
+                         int n_slides, int n_classes, float alpha, float eps, float* loss, float* risk, mpo_stream_t stream);
+int mpo_ces_loss_backward(const float* hazards, const float* survs, const int64_t* label, const float* censorship,
+                          int n_slides, int n_classes, float alpha, float eps, const float* d_loss, int d_loss_is_scalar,
+                          float* d_hazards, float* d_survs, mpo_stream_t stream);
+
 /* ---- K3: ContextualAttentionGate.forward (models/blocks.py:232-253) on rows of (Q, Q_hat).
  * 12 pointers: fc1.0.weight,.bias, fc2.0.weight,.bias, fc3.0.weight,.bias, G.1.weight,.bias, E.1.weight,.bias,
  * fc_c.0.weight,.bias */

@@ -67,6 +67,16 @@ struct GateFn {
             default: return 1.0f;
         }
     }
+    // same result as operator() when the element's Philox word is already at hand (one draw serves four elements)
+    __device__ __forceinline__ float with_word(float gv, uint32_t w) const {
+        const bool keep = (float)(w >> 8) * (1.0f / 16777216.0f) >= p;
+        if (mode == MPO_GATE_RNG) return keep ? inv_keep : 0.f;
+        if (p <= 0.f) return gv > 0.f ? 1.0f : gv + 1.0f;                    // MPO_GATE_ELU_ADROP
+        if (!keep) return 0.f;
+        const float a = alpha_drop_a(p), u = (gv - alpha_drop_b(p)) / a;
+        return a * (u > 0.f ? 1.0f : u + 1.0f);
+    }
+    __device__ __forceinline__ bool draws() const { return mode == MPO_GATE_RNG || mode == MPO_GATE_ELU_ADROP; }
 };
 
 // One operand tile (32 rows x KC k) in flight in registers: 8 float4 per thread.
@@ -80,6 +90,21 @@ struct OperandStage {
             const int f = i * 256 + tid;
             int mn, k;
             if (KCONTIG) { mn = f >> 6; k = (f & 63) << 2; } else { k = f >> 3; mn = (f & 7) << 2; }
+            // the four elements of a float4 are consecutive in memory: one Philox draw covers them when aligned
+            const size_t idx0 = KCONTIG ? (size_t)(mn0 + mn) * ld + (k0 + k) : (size_t)(k0 + k) * ld + (mn0 + mn);
+            const bool live0 = KCONTIG ? (mn0 + mn < mn_lim && k0 + k < k_lim) : (k0 + k < k_lim && mn0 + mn < mn_lim);
+            if (gf.draws() && (idx0 & 3) == 0) {
+                if (!live0) continue;
+                const uint64_t ctr = gf.off + (idx0 >> 2);
+                const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
+                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool live = KCONTIG ? k0 + k + j < k_lim : mn0 + mn + j < mn_lim;
+                    if (live) v[i][j] *= gf.with_word(gf.g ? gf.g[idx0 + j] : 0.f, w[j]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int gmn = mn0 + mn + (KCONTIG ? 0 : j), gk = k0 + k + (KCONTIG ? j : 0);
@@ -161,6 +186,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g) {
     if ((int)blockIdx.y * BM >= g.M || (int)blockIdx.x * BN >= g.N) return;      // grouped launch: grid is the max extent
     __shared__ __attribute__((aligned(16))) float As[IMG_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[IMG_FLOATS];
+    __shared__ float bred[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -192,8 +218,12 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g) {
         }
         __syncthreads();
         const int kblocks = (min(KC, g.K - k0) + 15) >> 4;
-        if (g.bias_grad != nullptr && blockIdx.x == 0 && tid < BM) {
-            for (int k = 0; k < 16 * kblocks; ++k) bsum += A_KC ? As[tid * LDK + k] : As[k * LDM + tid];
+        if (g.bias_grad != nullptr && blockIdx.x == 0) {       // row sums of the staged A tile: 8 threads per row
+            const int row = tid & 31, part = tid >> 5, klen = 2 * kblocks;
+            float ps = 0.f;
+            for (int k = part * klen; k < (part + 1) * klen; ++k) ps += A_KC ? As[row * LDK + k] : As[k * LDM + row];
+            ps += __shfl_xor(ps, 32);                          // parts (2w, 2w+1) share a wave
+            if (lane < 32) bred[wave][lane] = ps;
         }
         for (int kk = 0; kk < kblocks; ++kk) {
             const f32x4 a = OperandStage<A_KC>::frag(As, 16 * wm + i16, kk, kq);
@@ -204,6 +234,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g) {
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
         }
         __syncthreads();
+        if (g.bias_grad != nullptr && blockIdx.x == 0 && tid < BM) bsum += bred[0][tid] + bred[1][tid] + bred[2][tid] + bred[3][tid];
     }
     // ---- epilogue: D col = lane&15, row = 4*(lane>>4) + r
     const int n = n0 + 16 * wn + i16;

@@ -202,3 +202,10 @@ int mpo_launch_bag_colacc_gated(const void* bag, int bag_f32, const int* cu, int
 int mpo_launch_bag_outer_gated(const float* kbag, const int* cu, int n_slides, int embed, const float* w1, const float* z1,
                                const float* w2, const float* z2, void* dk, int dk_f32, int n_q, const BagPlan& plan,
                                hipStream_t stream);
+
+// 'ces' survival loss (tail.hip)
+int mpo_launch_ces_loss_fwd(const float* hazards, const float* survs, const long long* label, const float* cens, float* loss,
+                            float* risk, int B, int C, float alpha, float eps, hipStream_t s);
+int mpo_launch_ces_loss_bwd(const float* hazards, const float* survs, const long long* label, const float* cens,
+                            const float* d_loss, int d_loss_scalar, float* d_hazards, float* d_survs, int B, int C,
+                            float alpha, float eps, hipStream_t s);

@@ -285,6 +285,50 @@ __global__ void head_bwd_kernel(const float* __restrict__ hazards, const float* 
     for (int i = 0; i < C; ++i) dlogits[o + i] = dl[i];
 }
 
+// ------------------------------------------------------------------ 'ces' survival loss (models/loss.py:5-28), one thread per slide
+//   reg = -(1-c) (log max(S_pad[y], eps) + log max(h[y], eps)),  S_pad = [1, S]
+//   ce  = -(c log s + (1-c) log(1 - s)),  s = max(S[y], eps)
+//   loss = (1 - alpha) ce + alpha reg;   risk = -sum_j S_j  (models/mcat/main.py:56)
+__global__ void ces_loss_fwd_kernel(const float* __restrict__ hazards, const float* __restrict__ survs,
+                                    const long long* __restrict__ label, const float* __restrict__ cens,
+                                    float* __restrict__ loss, float* __restrict__ risk, int B, int C, float alpha, float eps) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t o = (size_t)b * C;
+    const int y = (int)label[b];
+    const float c = cens[b];
+    const float s_prev = y == 0 ? 1.0f : survs[o + y - 1];
+    const float reg = -(1.0f - c) * (logf(fmaxf(s_prev, eps)) + logf(fmaxf(hazards[o + y], eps)));
+    const float sy = fmaxf(survs[o + y], eps);
+    const float ce = -(c * logf(sy) + (1.0f - c) * logf(1.0f - sy));
+    loss[b] = (1.0f - alpha) * ce + alpha * reg;
+    if (risk) {
+        float r = 0.f;
+        for (int j = 0; j < C; ++j) r -= survs[o + j];
+        risk[b] = r;
+    }
+}
+// d_loss: per-slide upstream gradient (B) or, when d_loss_scalar, one value broadcast to every slide
+__global__ void ces_loss_bwd_kernel(const float* __restrict__ hazards, const float* __restrict__ survs,
+                                    const long long* __restrict__ label, const float* __restrict__ cens,
+                                    const float* __restrict__ d_loss, int d_loss_scalar, float* __restrict__ d_hazards,
+                                    float* __restrict__ d_survs, int B, int C, float alpha, float eps) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t o = (size_t)b * C;
+    const int y = (int)label[b];
+    const float c = cens[b];
+    const float g = d_loss_scalar ? d_loss[0] : d_loss[b];
+    for (int j = 0; j < C; ++j) { d_hazards[o + j] = 0.f; d_survs[o + j] = 0.f; }
+    const float hy = hazards[o + y], sy = survs[o + y];
+    if (hy >= eps) d_hazards[o + y] = -alpha * (1.0f - c) * g / hy;             // clamp(min=eps) passes gradient where x >= eps
+    if (y > 0) {
+        const float sp = survs[o + y - 1];
+        if (sp >= eps) d_survs[o + y - 1] = -alpha * (1.0f - c) * g / sp;
+    }
+    if (sy >= eps) d_survs[o + y] += -(1.0f - alpha) * g * (c / sy - (1.0f - c) / (1.0f - sy));
+}
+
 // ------------------------------------------------------------------ element-wise helpers
 __global__ void ew_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -428,6 +472,22 @@ int mpo_launch_head_bwd(const float* hazards, const float* survs, const float* y
                         const float* dy, float* dlogits, int B, int C, hipStream_t s) {
     MPO_CHECK(C >= 1 && C <= kMaxC, "survival head: n_classes %d not in 1..%d", C, kMaxC);
     head_bwd_kernel<<<(B + 63) / 64, 64, 0, s>>>(hazards, survs, y, dhz, dsv, dy, dlogits, B, C);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_ces_loss_fwd(const float* hazards, const float* survs, const long long* label, const float* cens, float* loss,
+                            float* risk, int B, int C, float alpha, float eps, hipStream_t s) {
+    MPO_CHECK(B >= 1 && C >= 1, "ces loss: empty batch (%d x %d)", B, C);
+    ces_loss_fwd_kernel<<<(B + 63) / 64, 64, 0, s>>>(hazards, survs, label, cens, loss, risk, B, C, alpha, eps);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_ces_loss_bwd(const float* hazards, const float* survs, const long long* label, const float* cens,
+                            const float* d_loss, int d_loss_scalar, float* d_hazards, float* d_survs, int B, int C,
+                            float alpha, float eps, hipStream_t s) {
+    MPO_CHECK(B >= 1 && C >= 1, "ces loss: empty batch (%d x %d)", B, C);
+    ces_loss_bwd_kernel<<<(B + 63) / 64, 64, 0, s>>>(hazards, survs, label, cens, d_loss, d_loss_scalar, d_hazards, d_survs,
+                                                     B, C, alpha, eps);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -336,6 +336,22 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- 'ces' loss
+int mpo_ces_loss_forward(const float* hazards, const float* survs, const int64_t* label, const float* censorship,
+                         int n_slides, int n_classes, float alpha, float eps, float* loss, float* risk, mpo_stream_t stream) {
+    MPO_CHECK(hazards && survs && label && censorship && loss, "ces loss forward: null argument");
+    return mpo_launch_ces_loss_fwd(hazards, survs, reinterpret_cast<const long long*>(label), censorship, loss, risk,
+                                   n_slides, n_classes, alpha, eps, static_cast<hipStream_t>(stream));
+}
+int mpo_ces_loss_backward(const float* hazards, const float* survs, const int64_t* label, const float* censorship,
+                          int n_slides, int n_classes, float alpha, float eps, const float* d_loss, int d_loss_is_scalar,
+                          float* d_hazards, float* d_survs, mpo_stream_t stream) {
+    MPO_CHECK(hazards && survs && label && censorship && d_loss && d_hazards && d_survs, "ces loss backward: null argument");
+    return mpo_launch_ces_loss_bwd(hazards, survs, reinterpret_cast<const long long*>(label), censorship, d_loss,
+                                   d_loss_is_scalar, d_hazards, d_survs, n_slides, n_classes, alpha, eps,
+                                   static_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------------------------------- K3 CAG
 // params: fc1.0.weight,.bias, fc2.0.weight,.bias, fc3.0.weight,.bias, G.1.weight,.bias, E.1.weight,.bias, fc_c.0.weight,.bias
 // saved: u1 u2 u3 t1 t3 G E m  [R,h each] | stats_g [R,2] | stats_e [R,2]

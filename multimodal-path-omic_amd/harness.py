@@ -70,9 +70,10 @@ def train_window(model, bags: BagBatch, omics, labels, cens, grad_acc_step: int)
     1/grad_acc_step scaling per slide (models/mcat/main.py:69-70).  Returns (per-slide loss, risk) tensors
     on the device -- no host sync."""
     hazards, survs, _, _ = model.forward_window(bags, omics)
-    per_slide = ces_loss(hazards, survs, labels, cens, reduction="none")
+    from . import ops
+    per_slide, risk = ops.ces_loss(hazards, survs, labels, cens)              # one HIP launch each way
     (per_slide.sum() / grad_acc_step).backward()
-    return per_slide.detach(), risk_score(survs.detach())
+    return per_slide.detach(), risk
 
 
 class GraphedWindowStep:

@@ -560,6 +560,47 @@ def omic_snn(omics, g_modules, training: bool):
     return OmicSnnFn.apply(p, len(omics), *[o.float() for o in omics], *params)
 
 
+class CesLossFn(torch.autograd.Function):
+    """'ces' loss (models/loss.py:5-28) for a whole window in one launch each way: per-slide losses + risks.
+    The torch formulation costs ~60 tiny launches per window (cat/gather/clamp/log and their backward)."""
+
+    @staticmethod
+    def forward(ctx, hazards, survs, label, censorship, alpha, eps):
+        lib = L.lib()
+        hazards, survs = hazards.contiguous(), survs.contiguous()
+        label = label.view(-1).to(torch.int64).contiguous()
+        censorship = censorship.view(-1).to(torch.float32).contiguous()
+        b, c = hazards.shape
+        loss = torch.empty(b, device=hazards.device, dtype=torch.float32)
+        risk = torch.empty(b, device=hazards.device, dtype=torch.float32)
+        L.check(lib.mpo_ces_loss_forward(L.ptr(hazards), L.ptr(survs), L.ptr(label), L.ptr(censorship), b, c, float(alpha),
+                                         float(eps), L.ptr(loss), L.ptr(risk), L.stream_of(hazards)), "mpo_ces_loss_forward")
+        ctx.save_for_backward(hazards, survs, label, censorship)
+        ctx.cfg = (float(alpha), float(eps))
+        ctx.mark_non_differentiable(risk)
+        return loss, risk
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_risk):
+        lib = L.lib()
+        hazards, survs, label, censorship = ctx.saved_tensors
+        alpha, eps = ctx.cfg
+        b, c = hazards.shape
+        # loss.sum().backward() hands an expanded (stride-0) gradient: pass its one element, no materialisation
+        scalar = d_loss.stride(0) == 0 and b > 1
+        d_loss = d_loss.as_strided((1,), (1,)) if scalar else d_loss.contiguous()
+        d_hz, d_sv = torch.empty_like(hazards), torch.empty_like(survs)
+        L.check(lib.mpo_ces_loss_backward(L.ptr(hazards), L.ptr(survs), L.ptr(label), L.ptr(censorship), b, c, alpha, eps,
+                                          L.ptr(d_loss), int(scalar), L.ptr(d_hz), L.ptr(d_sv), L.stream_of(hazards)),
+                "mpo_ces_loss_backward")
+        return d_hz, d_sv, None, None, None, None
+
+
+def ces_loss(hazards, survs, label, censorship, alpha: float = 0.75, eps: float = 1e-7):
+    """-> (per-slide 'ces' loss (B,), risk (B,)); reduce with .sum()/.mean() as the caller needs."""
+    return CesLossFn.apply(hazards, survs, label, censorship, alpha, eps)
+
+
 class FusionHeadFn(torch.autograd.Function):
     """K6: concat-fusion MLP + classifier + survival head."""
 

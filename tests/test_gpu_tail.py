@@ -192,3 +192,45 @@ def test_omic_snn_matches_stock_modules_and_alpha_dropout(dev):
     eps = 1e-3
     num = (f(eps) - f(-eps)) / (2 * eps)
     assert abs(ana - num) < 3e-2 * max(1.0, abs(num)), (ana, num)
+
+
+def test_ces_loss_kernel_matches_reference_kat_golden_and_oracle_gradients(dev, golden):
+    """'ces' loss in one launch each way (mpo_ces_loss_*): the reference's own known answers (models/loss.py:104-123),
+    the golden per-slide values, and gradients against the oracle incl. the clamp(min=eps) edges and the
+    broadcast (loss.sum()/acc) upstream gradient."""
+    from oracle import mpo_oracle as O
+    hz = torch.tensor([[0.51, 0.52, 0.49, 0.48]], device=dev)
+    s = torch.tensor([[0.5, 0.4, 0.2, 0.1]], device=dev)
+    y0 = torch.tensor([0], device=dev)
+    assert ops.ces_loss(hz, s, y0, torch.tensor([0.0], device=dev))[0].item() == pytest.approx(0.6782951951026917, abs=1e-6)
+    assert ops.ces_loss(hz, s, y0, torch.tensor([1.0], device=dev))[0].item() == pytest.approx(0.1732867956161499, abs=1e-6)
+    g = golden("loss")
+    hz_all = g["hazards"].reshape(8, 4)
+    sv_all = torch.cumprod(1 - hz_all, dim=1)
+    y = torch.arange(8) % 4
+    c = (torch.arange(8) // 4).float()
+    per, risk = ops.ces_loss(hz_all.to(dev), sv_all.to(dev), y.to(dev), c.to(dev))
+    for i in range(8):
+        assert per[i].item() == pytest.approx(float(g[f"ces/{i}"]), rel=1e-5, abs=1e-6)
+    torch.testing.assert_close(risk.cpu(), -sv_all.sum(1), rtol=1e-6, atol=1e-6)
+    # gradients: random slides plus rows that sit below eps (clamped: no gradient flows there)
+    gen = torch.Generator().manual_seed(5)
+    hz_r = torch.rand(32, 4, generator=gen) * 0.98 + 0.01
+    hz_r[3, 2] = 1e-9
+    hz_r[7] = torch.tensor([1.0 - 1e-9, 0.5, 0.5, 0.5])           # S collapses below eps from class 0 on
+    y_r = torch.randint(0, 4, (32,), generator=gen)
+    y_r[3], y_r[7] = 2, 1
+    c_r = torch.randint(0, 2, (32,), generator=gen).float()
+    w = torch.rand(32, generator=gen)
+    for weights in (w, None):
+        hz_o = hz_r.clone().requires_grad_(True)
+        sv_o = torch.cumprod(1 - hz_r, dim=1).requires_grad_(True)
+        per_o = torch.stack([O.ces_loss(hz_o[i:i + 1], sv_o[i:i + 1], y_r[i:i + 1], c_r[i:i + 1]) for i in range(32)])
+        ((per_o * weights).sum() if weights is not None else per_o.sum() / 8).backward()
+        hz_d = hz_r.to(dev).requires_grad_(True)
+        sv_d = sv_o.detach().to(dev).requires_grad_(True)
+        per_d, _ = ops.ces_loss(hz_d, sv_d, y_r.to(dev), c_r.to(dev))
+        torch.testing.assert_close(per_d.cpu(), per_o.detach(), rtol=1e-5, atol=1e-6)
+        ((per_d * weights.to(dev)).sum() if weights is not None else per_d.sum() / 8).backward()
+        torch.testing.assert_close(hz_d.grad.cpu(), hz_o.grad, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(sv_d.grad.cpu(), sv_o.grad, rtol=1e-5, atol=1e-7)
