@@ -255,11 +255,12 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
     const float scale = 1.0f / sqrtf((float)E);
     int rc;
     // out = attn W_o^T + b_o
-    if ((rc = mpo_linear_bwd_input(d_out, out_w, dattn, R, E, E, 1.0f, 0, stream))) return rc;
-    if ((rc = mpo_linear_bwd_weight(d_out, attn, d_out_w, d_out_b, R, E, E, 1.0f, stream))) return rc;
+    if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(d_out, out_w, dattn, R, E, E, 1.0f, 0),
+                                  mpo_args_bwd_weight(d_out, attn, d_out_w, d_out_b, R, E, E, 1.0f), stream))) return rc;
     // attn = ctx W_v^T + b_v
-    if ((rc = mpo_linear_bwd_input(dattn, w_v, dctx, R, E, E, 1.0f, 0, stream))) return rc;
-    if ((rc = mpo_linear_bwd_weight(dattn, ctx, d_in_w + (size_t)2 * E * E, d_in_b + 2 * E, R, E, E, 1.0f, stream))) return rc;
+    if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dattn, w_v, dctx, R, E, E, 1.0f, 0),
+                                  mpo_args_bwd_weight(dattn, ctx, d_in_w + (size_t)2 * E * E, d_in_b + 2 * E, R, E, E, 1.0f),
+                                  stream))) return rc;
     // delta = rowsum(dctx * ctx) [+ rowsum(A * dA_ext)]
     if ((rc = mpo_launch_rowdot(dctx, ctx, delta, R, E, stream))) return rc;
     if (d_attn_map)
@@ -269,12 +270,12 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                                     d_attn_map, d_bag, part_dqk, n_q, plan, bag_relu_gate, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part_dqk, dqk, n_slides, n_q, E, plan, stream))) return rc;
     // qk = qs W_k :  dqs = dqk W_k^T (folded with the 1/sqrt(E) of qs = scale * (...)),  dW_k = qs^T dqk,  db_k = 0
-    if ((rc = mpo_linear_fwd(dqk, w_k, nullptr, dq_pre, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
-    if ((rc = mpo_linear_bwd_weight(qs, dqk, d_in_w + (size_t)E * E, nullptr, R, E, E, 1.0f, stream))) return rc;
+    if ((rc = mpo_gemm_together(stream, mpo_args_fwd(dqk, w_k, nullptr, dq_pre, R, E, E, scale, MPO_ACT_NONE),
+                                mpo_args_bwd_weight(qs, dqk, d_in_w + (size_t)E * E, nullptr, R, E, E, 1.0f)))) return rc;
     MPO_HIP(hipMemsetAsync(d_in_b + E, 0, (size_t)E * sizeof(float), stream));
     // q_pre = query W_q^T + b_q
-    if ((rc = mpo_linear_bwd_input(dq_pre, w_q, d_query, R, E, E, 1.0f, 0, stream))) return rc;
-    if ((rc = mpo_linear_bwd_weight(dq_pre, query, d_in_w, d_in_b, R, E, E, 1.0f, stream))) return rc;
+    if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dq_pre, w_q, d_query, R, E, E, 1.0f, 0),
+                                  mpo_args_bwd_weight(dq_pre, query, d_in_w, d_in_b, R, E, E, 1.0f), stream))) return rc;
     return 0;
 }
 
@@ -385,13 +386,16 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     (void)qs2;
     int rc;
     // out = attn W_o^T + b_o
-    if ((rc = mpo_linear_bwd_input(d_out, out_w, dattn, R, E, E, 1.0f, 0, stream))) return rc;
-    if ((rc = mpo_linear_bwd_weight(d_out, attn, d_out_w, d_out_b, R, E, E, 1.0f, stream))) return rc;
+    if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(d_out, out_w, dattn, R, E, E, 1.0f, 0),
+                                  mpo_args_bwd_weight(d_out, attn, d_out_w, d_out_b, R, E, E, 1.0f), stream))) return rc;
     // attn = ctx W_v^T + asum (x) b_v
-    if ((rc = mpo_linear_bwd_input(dattn, w_v, dctx, R, E, E, 1.0f, 0, stream))) return rc;
-    if ((rc = mpo_linear_bwd_weight(dattn, ctx, d_in_w + (size_t)2 * E * E, nullptr, R, E, E, 1.0f, stream))) return rc;
-    if ((rc = mpo_linear_bwd_weight(asum, dattn, d_in_b + 2 * E, nullptr, R, E, 1, 1.0f, stream))) return rc;   // db_v = asum^T dattn
-    if ((rc = mpo_linear_fwd(dattn, b_v, nullptr, dasum, R, E, 1, 1.0f, MPO_ACT_NONE, stream))) return rc;        // dasum = dattn b_v
+    {
+        const GemmArgs dbv = mpo_args_bwd_weight(asum, dattn, d_in_b + 2 * E, nullptr, R, E, 1, 1.0f);       // db_v = asum^T dattn
+        const GemmArgs das = mpo_args_fwd(dattn, b_v, nullptr, dasum, R, E, 1, 1.0f, MPO_ACT_NONE);           // dasum = dattn b_v
+        if ((rc = mpo_gemm_together(stream, mpo_args_bwd_input(dattn, w_v, dctx, R, E, E, 1.0f, 0),
+                                    mpo_args_bwd_weight(dattn, ctx, d_in_w + (size_t)2 * E * E, nullptr, R, E, E, 1.0f),
+                                    &dbv, &das))) return rc;
+    }
     // map side
     if ((rc = mpo_launch_bag_rowdot(hbag, f32, cu_rows, n_slides, E, dctx, ds1_map, 1.0f, n_q, splits, stream))) return rc;
     if ((rc = mpo_launch_gated_softmax_bwd(a_map, g_map, cu_rows, lse2, dasum, d_attn_map, ds1_map, dg_map, n_slides, n_q,
@@ -402,8 +406,8 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     if ((rc = mpo_launch_coattn_bwd_reduce(part, dqt, n_slides, n_q, E, splits, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part2, dtq, n_slides, n_q, E, splits, stream))) return rc;
     if ((rc = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
-    if ((rc = mpo_linear_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0, stream))) return rc;
-    if ((rc = mpo_linear_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f, stream))) return rc;
+    if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0),
+                                  mpo_args_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f), stream))) return rc;
     // bag side: dK = ds1^T q~ + (dg^T tq) * (1 - TK^2),  dH = A_drop^T dctx
     // (one pass: tanh' from the staged K tile)
     if ((rc = mpo_launch_bag_outer_gated(static_cast<const float*>(kbag), cu_rows, n_slides, E, ds1_map, qt, dg_map, tq,

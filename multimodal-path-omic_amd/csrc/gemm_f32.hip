@@ -166,27 +166,49 @@ struct OperandStage {
     }
 };
 
+struct GemmLds {
+    __attribute__((aligned(16))) float As[IMG_FLOATS];
+    __attribute__((aligned(16))) float Bs[IMG_FLOATS];
+    float bred[4][32];
+};
+
 template <bool A_KC, bool B_KC>
-__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g);
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, GemmLds& lds);
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256)
 void gemm_f32_kernel(GemmArgs g) {
-    gemm_f32_body<A_KC, B_KC>(g);
+    __shared__ GemmLds lds;
+    gemm_f32_body<A_KC, B_KC>(g, lds);
 }
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256)
 void gemm_f32_group_kernel(GemmGroup grp) {
-    gemm_f32_body<A_KC, B_KC>(grp.g[blockIdx.z]);
+    __shared__ GemmLds lds;
+    gemm_f32_body<A_KC, B_KC>(grp.g[blockIdx.z], lds);
+}
+
+// members of DIFFERENT operand layouts in one launch (GemmArgs::layout): a layer's dx and dW products, which
+// both hang off the same dy, cost one dispatch instead of two on the latency-bound token tail
+__global__ __launch_bounds__(256)
+void gemm_f32_mixed_kernel(GemmGroup grp) {
+    __shared__ GemmLds lds;
+    const GemmArgs& g = grp.g[blockIdx.z];
+    switch (g.layout) {
+        case 3: gemm_f32_body<true, true>(g, lds); break;
+        case 2: gemm_f32_body<true, false>(g, lds); break;
+        case 1: gemm_f32_body<false, true>(g, lds); break;
+        default: gemm_f32_body<false, false>(g, lds); break;
+    }
 }
 
 template <bool A_KC, bool B_KC>
-__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, GemmLds& lds) {
     if ((int)blockIdx.y * BM >= g.M || (int)blockIdx.x * BN >= g.N) return;      // grouped launch: grid is the max extent
-    __shared__ __attribute__((aligned(16))) float As[IMG_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[IMG_FLOATS];
-    __shared__ float bred[4][32];
+    float* As = lds.As;
+    float* Bs = lds.Bs;
+    float (*bred)[32] = lds.bred;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -309,6 +331,22 @@ int mpo_launch_gemm_group(const GemmGroup& grp, int a_kc, int b_kc, hipStream_t 
     else if (a_kc && !b_kc) gemm_f32_group_kernel<true, false><<<grid, 256, 0, stream>>>(grp);
     else if (!a_kc && b_kc) gemm_f32_group_kernel<false, true><<<grid, 256, 0, stream>>>(grp);
     else gemm_f32_group_kernel<false, false><<<grid, 256, 0, stream>>>(grp);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_gemm_mixed(const GemmGroup& grp, hipStream_t stream) {
+    MPO_CHECK(grp.n >= 1 && grp.n <= 8, "mixed grouped gemm: 1..8 members (got %d)", grp.n);
+    int mx = 0, nx = 0;
+    for (int i = 0; i < grp.n; ++i) {
+        MPO_CHECK(grp.g[i].K > 0, "mixed grouped gemm: member %d has K = %d", i, grp.g[i].K);
+        MPO_CHECK(grp.g[i].layout >= 0 && grp.g[i].layout <= 3, "mixed grouped gemm: member %d has layout %d", i, grp.g[i].layout);
+        if (grp.g[i].M > mx) mx = grp.g[i].M;
+        if (grp.g[i].N > nx) nx = grp.g[i].N;
+    }
+    if (mx <= 0 || nx <= 0) return 0;
+    dim3 grid((nx + BN - 1) / BN, (mx + BM - 1) / BM, grp.n);
+    gemm_f32_mixed_kernel<<<grid, 256, 0, stream>>>(grp);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -45,6 +45,8 @@ struct GemmArgs {
     float* bias_grad = nullptr;
     // optional device-resident epoch added (x 2^40) to both dropout offsets (graph replay; mpo_common.h)
     const unsigned long long* rng_epoch = nullptr;
+    // operand layout for mpo_launch_gemm_mixed: 2 * a_kc + b_kc
+    int layout = 3;
 };
 
 struct DropSpec {                      // one dropout stream: p = 0 means "no dropout"
@@ -67,38 +69,70 @@ struct GemmGroup {
     int n = 0;
 };
 int mpo_launch_gemm_group(const GemmGroup& grp, int a_kc, int b_kc, hipStream_t stream);
+// members may differ in operand layout (GemmArgs::layout)
+int mpo_launch_gemm_mixed(const GemmGroup& grp, hipStream_t stream);
 int mpo_launch_colsum(const float* x, float* out, int M, int N, int ld, int accumulate, hipStream_t stream);
 
 // y[R][O] = drop(act(alpha * (x[R][I] W[O][I]^T + b))) [+ residual]
-inline int mpo_linear_fwd(const float* x, const float* w, const float* b, float* y, int R, int I, int O,
-                          float alpha, int act, hipStream_t s, const float* residual = nullptr,
-                          DropSpec drop = DropSpec()) {
+inline GemmArgs mpo_args_fwd(const float* x, const float* w, const float* b, float* y, int R, int I, int O,
+                             float alpha, int act, const float* residual = nullptr, DropSpec drop = DropSpec()) {
     GemmArgs g;
     g.A = x; g.B = w; g.C = y; g.bias = b; g.residual = residual;
     g.M = R; g.N = O; g.K = I; g.lda = I; g.ldb = I; g.ldc = O; g.alpha = alpha; g.act = act;
     g.drop_p = drop.p; g.drop_seed = drop.seed; g.drop_off = drop.off; g.rng_epoch = drop.epoch;
-    return mpo_launch_gemm(g, 1, 1, s);
+    g.layout = 3;
+    return g;
+}
+inline int mpo_linear_fwd(const float* x, const float* w, const float* b, float* y, int R, int I, int O,
+                          float alpha, int act, hipStream_t s, const float* residual = nullptr,
+                          DropSpec drop = DropSpec()) {
+    return mpo_launch_gemm(mpo_args_fwd(x, w, b, y, R, I, O, alpha, act, residual, drop), 1, 1, s);
 }
 // dx[R][I] (+)= alpha * (dy*gate)[R][O] W[O][I]
-inline int mpo_linear_bwd_input(const float* dy, const float* w, float* dx, int R, int I, int O, float alpha,
-                                int accumulate, hipStream_t s, GateSpec gate = GateSpec()) {
+inline GemmArgs mpo_args_bwd_input(const float* dy, const float* w, float* dx, int R, int I, int O, float alpha,
+                                   int accumulate, GateSpec gate = GateSpec()) {
     GemmArgs g;
     g.A = dy; g.B = w; g.C = dx;
     g.M = R; g.N = I; g.K = O; g.lda = O; g.ldb = I; g.ldc = I; g.alpha = alpha; g.accumulate = accumulate;
     g.gate = gate.g; g.gate_mode = gate.mode; g.gate_p = gate.p; g.gate_seed = gate.seed; g.gate_off = gate.off;
     g.rng_epoch = gate.epoch;
-    return mpo_launch_gemm(g, 1, 0, s);
+    g.layout = 2;
+    return g;
+}
+inline int mpo_linear_bwd_input(const float* dy, const float* w, float* dx, int R, int I, int O, float alpha,
+                                int accumulate, hipStream_t s, GateSpec gate = GateSpec()) {
+    return mpo_launch_gemm(mpo_args_bwd_input(dy, w, dx, R, I, O, alpha, accumulate, gate), 1, 0, s);
 }
 // dW[O][I] = alpha * (dy*gate)[R][O]^T x[R][I],   db[O] = column sums of dy*gate (nullable)
-inline int mpo_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int R, int I, int O,
-                                 float alpha, hipStream_t s, GateSpec gate = GateSpec()) {
+inline GemmArgs mpo_args_bwd_weight(const float* dy, const float* x, float* dw, float* db, int R, int I, int O,
+                                    float alpha, GateSpec gate = GateSpec()) {
     GemmArgs g;
     g.A = dy; g.B = x; g.C = dw;
     g.M = O; g.N = I; g.K = R; g.lda = O; g.ldb = I; g.ldc = I; g.alpha = alpha;
     g.gate = gate.g; g.gate_mode = gate.mode; g.gate_p = gate.p; g.gate_seed = gate.seed; g.gate_off = gate.off;
     g.rng_epoch = gate.epoch;
     g.bias_grad = db;
-    return mpo_launch_gemm(g, 0, 0, s);
+    g.layout = 0;
+    return g;
+}
+inline int mpo_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int R, int I, int O,
+                                 float alpha, hipStream_t s, GateSpec gate = GateSpec()) {
+    return mpo_launch_gemm(mpo_args_bwd_weight(dy, x, dw, db, R, I, O, alpha, gate), 0, 0, s);
+}
+// a layer's input- and weight-gradient products in ONE launch (both read the same dy)
+inline int mpo_linear_bwd_pair(const GemmArgs& dx, const GemmArgs& dw, hipStream_t s) {
+    GemmGroup grp;
+    grp.g[0] = dx; grp.g[1] = dw; grp.n = 2;
+    return mpo_launch_gemm_mixed(grp, s);
+}
+// up to four independent products of any layout in ONE launch
+inline int mpo_gemm_together(hipStream_t s, const GemmArgs& a, const GemmArgs& b, const GemmArgs* c = nullptr,
+                             const GemmArgs* d = nullptr) {
+    GemmGroup grp;
+    grp.g[0] = a; grp.g[1] = b; grp.n = 2;
+    if (c) grp.g[grp.n++] = *c;
+    if (d) grp.g[grp.n++] = *d;
+    return mpo_launch_gemm_mixed(grp, s);
 }
 
 // ---- K1/K2 long-bag cross-attention (coattn_fwd.hip / coattn_bwd.hip)
@@ -161,6 +195,7 @@ int mpo_launch_head_fwd(const float* logits, float* hazards, float* survs, float
 int mpo_launch_head_bwd(const float* hazards, const float* survs, const float* y, const float* dhz, const float* dsv,
                         const float* dy, float* dlogits, int B, int C, hipStream_t s);
 int mpo_launch_ew_mul(const float* a, const float* b, float* out, int n, hipStream_t s);
+int mpo_launch_ew_mul2(const float* x, const float* p, const float* q, float* xp, float* xq, int n, hipStream_t s);
 int mpo_launch_ew_add(const float* a, const float* b, float* out, int n, hipStream_t s);
 int mpo_launch_cag_mid_fwd(const float* u1, const float* u2, const float* u3, const float* gw, const float* gb, const float* ew,
                            const float* eb, float* t1, float* t3, float* gout, float* eout, float* m, float* stats_g, float* stats_e,

@@ -334,6 +334,11 @@ __global__ void ew_mul_kernel(const float* __restrict__ a, const float* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] * b[i];
 }
+__global__ void ew_mul2_kernel(const float* __restrict__ x, const float* __restrict__ p, const float* __restrict__ q,
+                               float* __restrict__ xp, float* __restrict__ xq, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = x[i]; xp[i] = v * p[i]; xq[i] = v * q[i]; }
+}
 __global__ void ew_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
@@ -493,6 +498,11 @@ int mpo_launch_ces_loss_bwd(const float* hazards, const float* survs, const long
 }
 int mpo_launch_ew_mul(const float* a, const float* b, float* out, int n, hipStream_t s) {
     ew_mul_kernel<<<(n + 255) / 256, 256, 0, s>>>(a, b, out, n);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_ew_mul2(const float* x, const float* p, const float* q, float* xp, float* xq, int n, hipStream_t s) {
+    ew_mul2_kernel<<<(n + 255) / 256, 256, 0, s>>>(x, p, q, xp, xq, n);
     MPO_LAUNCH_CHECK();
     return 0;
 }

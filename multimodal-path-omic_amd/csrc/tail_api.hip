@@ -60,6 +60,11 @@ inline GateSpec gate_rng(DropSpec d) {
 // another stream, with the SAME workspace), 3 = both in one call.
 #define MAIN(expr) do { if (phase & 1) RC(expr); } while (0)
 #define SIDE(expr) do { if (phase & 2) RC(expr); } while (0)
+// a layer's dx (layout 2) and dW (layout 0) products: one mixed launch when both phases run in this call
+#define PAIR(dxa, dwa) do { \
+        if (phase == 3) RC(mpo_linear_bwd_pair((dxa), (dwa), stream)); \
+        else { if (phase & 1) RC(mpo_launch_gemm((dxa), 1, 0, stream)); if (phase & 2) RC(mpo_launch_gemm((dwa), 0, 0, side.get())); } \
+    } while (0)
 struct SideSel {                        // stream for the weight-gradient launches of this call
     SideFork fork;
     hipStream_t main;
@@ -177,32 +182,30 @@ int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int
         MAIN(mpo_launch_ln_bwd(dcur, S[l].s2, S[l].st2, P[P_N2W], ds2, nullptr, nullptr, R, d, 0, stream));
         SIDE(mpo_launch_ln_bwd_params_only(dcur, S[l].s2, S[l].st2, G[P_N2W], G[P_N2B], R, d, side.get()));
         // s2 = x1 + drop3(f W2^T + b2)
-        MAIN(mpo_linear_bwd_input(ds2, P[P_L2W], df, R, ff, d, 1.0f, 0, stream, gate_rng(d3)));
-        SIDE(mpo_linear_bwd_weight(ds2, S[l].f, G[P_L2W], G[P_L2B], R, ff, d, 1.0f, side.get(), gate_rng(d3)));
+        PAIR(mpo_args_bwd_input(ds2, P[P_L2W], df, R, ff, d, 1.0f, 0, gate_rng(d3)),
+             mpo_args_bwd_weight(ds2, S[l].f, G[P_L2W], G[P_L2B], R, ff, d, 1.0f, gate_rng(d3)));
         // f = drop2(relu(x1 W1^T + b1));  dx1 = ds2 + (df*gate) W1
         {
             GemmArgs g;
             g.A = df; g.B = P[P_L1W]; g.C = dx1; g.residual = ds2;
             g.M = R; g.N = d; g.K = ff; g.lda = ff; g.ldb = d; g.ldc = d;
-            g.gate = S[l].f; g.gate_mode = MPO_GATE_RELU; g.gate_p = drop_p;
-            MAIN(mpo_launch_gemm(g, 1, 0, stream));
+            g.gate = S[l].f; g.gate_mode = MPO_GATE_RELU; g.gate_p = drop_p; g.layout = 2;
+            PAIR(g, mpo_args_bwd_weight(df, S[l].x1, G[P_L1W], G[P_L1B], R, d, ff, 1.0f, gate(S[l].f, MPO_GATE_RELU, drop_p)));
         }
-        SIDE(mpo_linear_bwd_weight(df, S[l].x1, G[P_L1W], G[P_L1B], R, d, ff, 1.0f, side.get(), gate(S[l].f, MPO_GATE_RELU, drop_p)));
         // x1 = LN1(s1)
         MAIN(mpo_launch_ln_bwd(dx1, S[l].s1, S[l].st1, P[P_N1W], ds1, nullptr, nullptr, R, d, 0, stream));
         SIDE(mpo_launch_ln_bwd_params_only(dx1, S[l].s1, S[l].st1, G[P_N1W], G[P_N1B], R, d, side.get()));
         // s1 = in + drop1(o W_o^T + b_o)
-        MAIN(mpo_linear_bwd_input(ds1, P[P_OUTW], dob, R, d, d, 1.0f, 0, stream, gate_rng(d1)));
-        SIDE(mpo_linear_bwd_weight(ds1, S[l].o, G[P_OUTW], G[P_OUTB], R, d, d, 1.0f, side.get(), gate_rng(d1)));
+        PAIR(mpo_args_bwd_input(ds1, P[P_OUTW], dob, R, d, d, 1.0f, 0, gate_rng(d1)),
+             mpo_args_bwd_weight(ds1, S[l].o, G[P_OUTW], G[P_OUTB], R, d, d, 1.0f, gate_rng(d1)));
         MAIN(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, n_slides, T, d, heads, stream));
         // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in
         {
             GemmArgs g;
             g.A = dqkv; g.B = P[P_INW]; g.C = din; g.residual = ds1;
-            g.M = R; g.N = d; g.K = 3 * d; g.lda = 3 * d; g.ldb = d; g.ldc = d;
-            MAIN(mpo_launch_gemm(g, 1, 0, stream));
+            g.M = R; g.N = d; g.K = 3 * d; g.lda = 3 * d; g.ldb = d; g.ldc = d; g.layout = 2;
+            PAIR(g, mpo_args_bwd_weight(dqkv, in, G[P_INW], G[P_INB], R, d, 3 * d, 1.0f));
         }
-        SIDE(mpo_linear_bwd_weight(dqkv, in, G[P_INW], G[P_INB], R, d, 3 * d, 1.0f, side.get()));
         dcur = din;
     }
     RC(side.join());
@@ -236,8 +239,9 @@ int mpo_gated_pool_forward(const float* x, int n_slides, int L, int d, const flo
     Carver c(saved);
     float* a = c.take((size_t)R * d); float* b = c.take((size_t)R * d); float* ab = c.take((size_t)R * d);
     float* w = c.take(R); float* hpool = c.take((size_t)n_slides * d);
-    RC(mpo_linear_fwd(x, P[0], P[1], a, R, d, d, 1.0f, MPO_ACT_TANH, stream, nullptr, stream_of(head_drop_p, seed, offset, stride, 0, rng_epoch)));
-    RC(mpo_linear_fwd(x, P[2], P[3], b, R, d, d, 1.0f, MPO_ACT_SIGMOID, stream, nullptr, stream_of(head_drop_p, seed, offset, stride, 1, rng_epoch)));
+    RC(mpo_gemm_together(stream,
+        mpo_args_fwd(x, P[0], P[1], a, R, d, d, 1.0f, MPO_ACT_TANH, nullptr, stream_of(head_drop_p, seed, offset, stride, 0, rng_epoch)),
+        mpo_args_fwd(x, P[2], P[3], b, R, d, d, 1.0f, MPO_ACT_SIGMOID, nullptr, stream_of(head_drop_p, seed, offset, stride, 1, rng_epoch))));
     RC(mpo_launch_ew_mul(a, b, ab, R * d, stream));
     RC(mpo_linear_fwd(ab, P[4], P[5], scores, R, d, 1, 1.0f, MPO_ACT_NONE, stream));
     RC(mpo_launch_pool_fwd(scores, x, w, hpool, n_slides, L, d, stream));
@@ -263,21 +267,28 @@ int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const fl
     MPO_CHECK(dhpool && dscores && dab && da && db, "gated pool backward: workspace too small (%zu bytes)", workspace_bytes);
     SideSel side(stream, phase);                            // weight gradients beside the dx chain (no buffer is rewritten)
     // h = drop(relu(hpool W_rho^T + b_rho))
-    SIDE(mpo_linear_bwd_weight(dh, hpool, G[6], G[7], n_slides, d, d, 1.0f, side.get(), gate(h, MPO_GATE_RELU, rho_drop_p)));
-    MAIN(mpo_linear_bwd_input(dh, P[6], dhpool, n_slides, d, d, 1.0f, 0, stream, gate(h, MPO_GATE_RELU, rho_drop_p)));
+    PAIR(mpo_args_bwd_input(dh, P[6], dhpool, n_slides, d, d, 1.0f, 0, gate(h, MPO_GATE_RELU, rho_drop_p)),
+         mpo_args_bwd_weight(dh, hpool, G[6], G[7], n_slides, d, d, 1.0f, gate(h, MPO_GATE_RELU, rho_drop_p)));
     MAIN(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, n_slides, L, d, stream));
     // scores = ab W_c^T + b_c
-    SIDE(mpo_linear_bwd_weight(dscores, ab, G[4], G[5], R, d, 1, 1.0f, side.get()));
-    MAIN(mpo_linear_bwd_input(dscores, P[4], dab, R, d, 1, 1.0f, 0, stream));
-    MAIN(mpo_launch_ew_mul(dab, b, da, R * d, stream));
-    MAIN(mpo_launch_ew_mul(dab, a, db, R * d, stream));
-    {
+    PAIR(mpo_args_bwd_input(dscores, P[4], dab, R, d, 1, 1.0f, 0), mpo_args_bwd_weight(dscores, ab, G[4], G[5], R, d, 1, 1.0f));
+    MAIN(mpo_launch_ew_mul2(dab, b, a, da, db, R * d, stream));                  // da = dab * b,  db = dab * a
+    const GemmArgs dxa = mpo_args_bwd_input(da, P[0], dx, R, d, d, 1.0f, 1, gate(a, MPO_GATE_TANH, head_drop_p));
+    const GemmArgs dxb = mpo_args_bwd_input(db, P[2], dx, R, d, d, 1.0f, 1, gate(b, MPO_GATE_SIGMOID, head_drop_p));
+    const GemmArgs dwa = mpo_args_bwd_weight(da, x, G[0], G[1], R, d, d, 1.0f, gate(a, MPO_GATE_TANH, head_drop_p));
+    const GemmArgs dwb = mpo_args_bwd_weight(db, x, G[2], G[3], R, d, d, 1.0f, gate(b, MPO_GATE_SIGMOID, head_drop_p));
+    if (phase == 3) {                                       // dx accumulates twice: the second product follows alone
+        GemmGroup grp;
+        grp.g[0] = dxa; grp.g[1] = dwa; grp.g[2] = dwb; grp.n = 3;
+        RC(mpo_launch_gemm_mixed(grp, stream));
+        RC(mpo_launch_gemm(dxb, 1, 0, stream));
+    } else {
         hipStream_t ss = side.get();
-        SIDE(mpo_linear_bwd_weight(da, x, G[0], G[1], R, d, d, 1.0f, ss, gate(a, MPO_GATE_TANH, head_drop_p)));
-        SIDE(mpo_linear_bwd_weight(db, x, G[2], G[3], R, d, d, 1.0f, ss, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
+        SIDE(mpo_launch_gemm(dwa, 0, 0, ss));
+        SIDE(mpo_launch_gemm(dwb, 0, 0, ss));
+        MAIN(mpo_launch_gemm(dxa, 1, 0, stream));
+        MAIN(mpo_launch_gemm(dxb, 1, 0, stream));
     }
-    MAIN(mpo_linear_bwd_input(da, P[0], dx, R, d, d, 1.0f, 1, stream, gate(a, MPO_GATE_TANH, head_drop_p)));
-    MAIN(mpo_linear_bwd_input(db, P[2], dx, R, d, d, 1.0f, 1, stream, gate(b, MPO_GATE_SIGMOID, head_drop_p)));
     RC(side.join());
     return 0;
 }
@@ -326,12 +337,12 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
     MPO_CHECK(dlogits && dz2 && dz1, "fusion head backward: workspace too small (%zu bytes)", workspace_bytes);
     SideSel side(stream, phase);
     MAIN(mpo_launch_head_bwd(hazards, survs, y, d_hazards, d_survs, d_y, dlogits, n_slides, n_classes, stream));
-    SIDE(mpo_linear_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f, side.get()));
-    MAIN(mpo_linear_bwd_input(dlogits, P[4], dz2, n_slides, dout, n_classes, 1.0f, 0, stream));
-    SIDE(mpo_linear_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, side.get(), gate(z2, MPO_GATE_RELU)));
-    MAIN(mpo_linear_bwd_input(dz2, P[2], dz1, n_slides, hidden, dout, 1.0f, 0, stream, gate(z2, MPO_GATE_RELU)));
-    SIDE(mpo_linear_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, side.get(), gate(z1, MPO_GATE_RELU)));
-    MAIN(mpo_linear_bwd_input(dz1, P[0], d_hcat, n_slides, din, hidden, 1.0f, 0, stream, gate(z1, MPO_GATE_RELU)));
+    PAIR(mpo_args_bwd_input(dlogits, P[4], dz2, n_slides, dout, n_classes, 1.0f, 0),
+         mpo_args_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f));
+    PAIR(mpo_args_bwd_input(dz2, P[2], dz1, n_slides, hidden, dout, 1.0f, 0, gate(z2, MPO_GATE_RELU)),
+         mpo_args_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, gate(z2, MPO_GATE_RELU)));
+    PAIR(mpo_args_bwd_input(dz1, P[0], d_hcat, n_slides, din, hidden, 1.0f, 0, gate(z1, MPO_GATE_RELU)),
+         mpo_args_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, gate(z1, MPO_GATE_RELU)));
     RC(side.join());
     return 0;
 }
@@ -375,9 +386,11 @@ int mpo_cag_forward(const float* q, const float* q_hat, int rows, int dim, int h
     float* t1 = c.take((size_t)rows * hidden); float* t3 = c.take((size_t)rows * hidden);
     float* g = c.take((size_t)rows * hidden); float* e = c.take((size_t)rows * hidden); float* m = c.take((size_t)rows * hidden);
     float* sg = c.take(2 * (size_t)rows); float* se = c.take(2 * (size_t)rows);
-    RC(mpo_linear_fwd(q, P[0], P[1], u1, rows, dim, hidden, 1.0f, MPO_ACT_ELU, stream));
-    RC(mpo_linear_fwd(q_hat, P[2], P[3], u2, rows, dim, hidden, 1.0f, MPO_ACT_ELU, stream));
-    RC(mpo_linear_fwd(q_hat, P[4], P[5], u3, rows, dim, hidden, 1.0f, MPO_ACT_ELU, stream));
+    {
+        const GemmArgs g3 = mpo_args_fwd(q_hat, P[4], P[5], u3, rows, dim, hidden, 1.0f, MPO_ACT_ELU);
+        RC(mpo_gemm_together(stream, mpo_args_fwd(q, P[0], P[1], u1, rows, dim, hidden, 1.0f, MPO_ACT_ELU),
+                             mpo_args_fwd(q_hat, P[2], P[3], u2, rows, dim, hidden, 1.0f, MPO_ACT_ELU), &g3));
+    }
     RC(mpo_launch_cag_mid_fwd(u1, u2, u3, P[6], P[7], P[8], P[9], t1, t3, g, e, m, sg, se, rows, hidden, 1e-5f, stream));
     RC(mpo_linear_fwd(m, P[10], P[11], c_out, rows, hidden, hidden, 1.0f, MPO_ACT_ELU, stream));
     return 0;
@@ -398,18 +411,23 @@ int mpo_cag_backward(const float* q, const float* q_hat, int rows, int dim, int 
     float* ds3 = ws.floats((size_t)rows * hidden);
     MPO_CHECK(dm && dG && dE && ds12 && ds3, "CAG backward: workspace too small (%zu bytes)", workspace_bytes);
     // C = ELU(m Wc^T + bc)
-    RC(mpo_linear_bwd_input(d_c, P[10], dm, rows, hidden, hidden, 1.0f, 0, stream, gate(c_out, MPO_GATE_ELU)));
-    RC(mpo_linear_bwd_weight(d_c, m, G[10], G[11], rows, hidden, hidden, 1.0f, stream, gate(c_out, MPO_GATE_ELU)));
+    RC(mpo_linear_bwd_pair(mpo_args_bwd_input(d_c, P[10], dm, rows, hidden, hidden, 1.0f, 0, gate(c_out, MPO_GATE_ELU)),
+                           mpo_args_bwd_weight(d_c, m, G[10], G[11], rows, hidden, hidden, 1.0f, gate(c_out, MPO_GATE_ELU)), stream));
     RC(mpo_launch_cag_mid_bwd(dm, t1, t3, g, e, P[6], P[8], sg, se, dG, dE, ds12, ds3, rows, hidden, stream));
     RC(mpo_launch_ln_bwd_params_only(dG, t1, sg, G[6], G[7], rows, hidden, stream));
     RC(mpo_launch_ln_bwd_params_only(dE, t3, se, G[8], G[9], rows, hidden, stream));
     // u1 = ELU(fc1 q), u2 = ELU(fc2 qh), u3 = ELU(fc3 qh)
-    RC(mpo_linear_bwd_input(ds12, P[0], d_q, rows, dim, hidden, 1.0f, 0, stream, gate(u1, MPO_GATE_ELU)));
-    RC(mpo_linear_bwd_weight(ds12, q, G[0], G[1], rows, dim, hidden, 1.0f, stream, gate(u1, MPO_GATE_ELU)));
-    RC(mpo_linear_bwd_input(ds12, P[2], d_q_hat, rows, dim, hidden, 1.0f, 0, stream, gate(u2, MPO_GATE_ELU)));
-    RC(mpo_linear_bwd_weight(ds12, q_hat, G[2], G[3], rows, dim, hidden, 1.0f, stream, gate(u2, MPO_GATE_ELU)));
+    {   // five independent products in one mixed launch; d_q_hat accumulates its second product afterwards
+        GemmGroup grp;
+        grp.g[0] = mpo_args_bwd_input(ds12, P[0], d_q, rows, dim, hidden, 1.0f, 0, gate(u1, MPO_GATE_ELU));
+        grp.g[1] = mpo_args_bwd_weight(ds12, q, G[0], G[1], rows, dim, hidden, 1.0f, gate(u1, MPO_GATE_ELU));
+        grp.g[2] = mpo_args_bwd_input(ds12, P[2], d_q_hat, rows, dim, hidden, 1.0f, 0, gate(u2, MPO_GATE_ELU));
+        grp.g[3] = mpo_args_bwd_weight(ds12, q_hat, G[2], G[3], rows, dim, hidden, 1.0f, gate(u2, MPO_GATE_ELU));
+        grp.g[4] = mpo_args_bwd_weight(ds3, q_hat, G[4], G[5], rows, dim, hidden, 1.0f, gate(u3, MPO_GATE_ELU));
+        grp.n = 5;
+        RC(mpo_launch_gemm_mixed(grp, stream));
+    }
     RC(mpo_linear_bwd_input(ds3, P[4], d_q_hat, rows, dim, hidden, 1.0f, 1, stream, gate(u3, MPO_GATE_ELU)));
-    RC(mpo_linear_bwd_weight(ds3, q_hat, G[4], G[5], rows, dim, hidden, 1.0f, stream, gate(u3, MPO_GATE_ELU)));
     return 0;
 }
 
