@@ -164,28 +164,34 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
 /* ---- K4: set-Transformer = nn.TransformerEncoder(post-norm layers, nhead, dim_feedforward, relu), no final
  * norm.  Replaces models/mcat/mcat.py:51-53,60-62 (call :101-102); torch/nn/modules/transformer.py:661.
  * x, y [n_slides*T, d]; per layer 12 pointers: self_attn.in_proj_weight, in_proj_bias, out_proj.weight,
- * out_proj.bias, linear1.weight, .bias, linear2.weight, .bias, norm1.weight, .bias, norm2.weight, .bias. */
+ * out_proj.bias, linear1.weight, .bias, linear2.weight, .bias, norm1.weight, .bias, norm2.weight, .bias.
+ * n_branches (1..4) batches that many independent encoders of IDENTICAL geometry -- the model's path_transformer
+ * and omic_transformer -- into one launch sequence: x, y are [n_branches][n_slides*T][d], params / grads hold
+ * n_branches * layers * 12 pointers (branch-major), and the *_floats / *_bytes / rng_span queries take
+ * n_branches * n_slides as their n_slides.  The token tail is launch-latency-bound, so the second branch is free. */
 size_t mpo_encoder_saved_floats(int n_slides, int T, int d, int ff, int heads, int layers);
 size_t mpo_encoder_workspace_bytes(int n_slides, int T, int d, int ff);
 uint64_t mpo_encoder_rng_span(int n_slides, int T, int d, int ff, int layers);
-int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
+int mpo_encoder_forward(const float* x, int n_branches, int n_slides, int T, int d, int ff, int heads, int layers,
                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                         float* y, float* saved, mpo_stream_t stream);
-int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
+int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, int d, int ff, int heads, int layers,
                          const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                          const float* saved, const float* dy, float* dx, float* const* grads, int phase,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ---- K5: gated attention-MIL pooling = AttentionNetGated (models/blocks.py:13-48) + softmax pooling + rho
  * (models/mcat/mcat.py:105-109).  x [n_slides*L, d] -> scores [n_slides*L] (raw A), h [n_slides, d].
- * 8 pointers: attention_a.0.weight, .bias, attention_b.0.weight, .bias, attention_c.weight, .bias, rho.0.weight, .bias */
+ * 8 pointers: attention_a.0.weight, .bias, attention_b.0.weight, .bias, attention_c.weight, .bias, rho.0.weight, .bias
+ * n_branches (forward 1..4, backward 1..2) batches independent heads of identical geometry as for K4: tensors are
+ * [n_branches][...], params / grads n_branches * 8 pointers, size queries take n_branches * n_slides. */
 size_t mpo_gated_pool_saved_floats(int n_slides, int L, int d);
 size_t mpo_gated_pool_workspace_bytes(int n_slides, int L, int d);
 uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d);
-int mpo_gated_pool_forward(const float* x, int n_slides, int L, int d, const float* const* params,
+int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                            float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                            float* scores, float* h, float* saved, mpo_stream_t stream);
-int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const float* const* params,
+int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                             float head_drop_p, float rho_drop_p, const float* saved, const float* h,
                             const float* dh, const float* d_scores_ext /* nullable */, float* dx, float* const* grads,
                             int phase, void* workspace, size_t workspace_bytes, mpo_stream_t stream);

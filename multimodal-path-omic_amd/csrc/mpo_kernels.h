@@ -177,6 +177,19 @@ int mpo_launch_qprep_bwd(const float* dqt, const float* dtq, const float* tq, co
 int mpo_launch_row_scaled_bias(float* y, const float* s, const float* bias, int rows, int cols, hipStream_t stream);
 
 // ---- tail kernels (tail.hip)
+// LayerNorm over rows that belong to up to kMaxBranches independent modules (branch = row / rows_per_branch)
+constexpr int kMaxBranches = 4;
+struct LnBranches {
+    const float* w[kMaxBranches] = {};
+    const float* b[kMaxBranches] = {};
+    float* dw[kMaxBranches] = {};
+    float* db[kMaxBranches] = {};
+    int rows_per_branch = 0, n = 0;
+};
+int mpo_launch_ln_fwd_br(const float* x, const LnBranches& p, float* y, float* stats, int rows, int d, float eps, hipStream_t s);
+// what: 1 = dx, 2 = parameter gradients, 3 = both in one launch
+int mpo_launch_ln_bwd_br(const float* dy, const float* x, const float* stats, const LnBranches& p, float* dx, int rows, int d,
+                         int accumulate, int what, hipStream_t s);
 int mpo_launch_ln_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int rows, int d, float eps,
                       hipStream_t s);
 int mpo_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* w, float* dx, float* dw, float* db,

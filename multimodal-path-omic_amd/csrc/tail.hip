@@ -13,11 +13,16 @@ __device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v)
 __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.0f : y + 1.0f; }
 
 // ------------------------------------------------------------------ LayerNorm (one wave per row)
-__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                              float* __restrict__ y, float* __restrict__ stats, int rows, int d, float eps) {
+// Rows may belong to several BRANCHES (independent modules of identical shape batched into one launch, e.g. the
+// path and the omic set-Transformer): branch = row / rows_per_branch picks the affine parameters.
+__global__ void ln_fwd_kernel(const float* __restrict__ x, LnBranches p, float* __restrict__ y, float* __restrict__ stats,
+                              int rows, int d, float eps) {
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
+    const int br = r / p.rows_per_branch;
+    const float* __restrict__ w = p.w[br];
+    const float* __restrict__ b = p.b[br];
     const float* xr = x + (size_t)r * d;
     float s = 0.f;
     for (int c = lane; c < d; c += 64) s += xr[c];
@@ -30,11 +35,13 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w    [dx may alias dy]
-__global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                              const float* __restrict__ w, float* __restrict__ dx, int rows, int d, int accumulate) {
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ __forceinline__ void ln_bwd_rows(int rb, const float* __restrict__ dy, const float* __restrict__ x,
+                                            const float* __restrict__ stats, const LnBranches& p, float* __restrict__ dx,
+                                            int rows, int d, int accumulate) {
+    const int r = rb * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
+    const float* __restrict__ w = p.w[r / p.rows_per_branch];
     const float mean = stats[2 * r], rstd = stats[2 * r + 1];
     float c1 = 0.f, c2 = 0.f;
     for (int c = lane; c < d; c += 64) {
@@ -53,17 +60,17 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
     }
 }
 
-// dw[c] = sum_r dy * xhat,  db[c] = sum_r dy.  16 columns per workgroup, 16 row groups of 16 lanes each (the
-// first version used 64 columns x 4 row groups = 4 workgroups for d = 256 and took 19 us on 192 rows).
-__global__ __launch_bounds__(256)
-void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                          float* __restrict__ dw, float* __restrict__ db, int rows, int d) {
+// dw[c] = sum_r dy * xhat,  db[c] = sum_r dy over the rows of one branch.  16 columns per workgroup, 16 row groups of
+// 16 lanes each (the first version used 64 columns x 4 row groups = 4 workgroups for d = 256 and took 19 us on 192 rows).
+__device__ __forceinline__ void ln_bwd_params_cols(int cb, int br, const float* __restrict__ dy, const float* __restrict__ x,
+                                                   const float* __restrict__ stats, const LnBranches& p, int d) {
     __shared__ float red[2][16][17];
     const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + c;
+    const int col = cb * 16 + c;
+    const int r0 = br * p.rows_per_branch, r1 = r0 + p.rows_per_branch;
     float a = 0.f, bsum = 0.f;
     if (col < d)
-        for (int r = rg; r < rows; r += 16) {
+        for (int r = r0 + rg; r < r1; r += 16) {
             const float g = dy[(size_t)r * d + col];
             a += g * (x[(size_t)r * d + col] - stats[2 * r]) * stats[2 * r + 1];
             bsum += g;
@@ -75,8 +82,20 @@ void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict_
         float ta = 0.f, tb = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) { ta += red[0][k][c]; tb += red[1][k][c]; }
-        dw[col] = ta;
-        db[col] = tb;
+        p.dw[br][col] = ta;
+        p.db[br][col] = tb;
+    }
+}
+// what: 1 = dx rows, 2 = parameter gradients, 3 = both in ONE launch (row blocks first, then column blocks)
+__global__ __launch_bounds__(256)
+void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats, LnBranches p,
+                   float* __restrict__ dx, int rows, int d, int accumulate, int what) {
+    const int row_blocks = (what & 1) ? (rows + 3) / 4 : 0;
+    if ((int)blockIdx.x < row_blocks) {
+        ln_bwd_rows(blockIdx.x, dy, x, stats, p, dx, rows, d, accumulate);
+    } else {
+        const int cblocks = (d + 15) / 16, i = blockIdx.x - row_blocks;
+        ln_bwd_params_cols(i % cblocks, i / cblocks, dy, x, stats, p, d);
     }
 }
 
@@ -415,29 +434,40 @@ __global__ void cag_mid_bwd_kernel(const float* __restrict__ dm, const float* __
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers
-int mpo_launch_ln_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int rows, int d, float eps,
-                      hipStream_t s) {
+int mpo_launch_ln_fwd_br(const float* x, const LnBranches& p, float* y, float* stats, int rows, int d, float eps, hipStream_t s) {
     if (rows <= 0) return 0;
-    ln_fwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(x, w, b, y, stats, rows, d, eps);
+    MPO_CHECK(p.n >= 1 && p.n <= kMaxBranches && p.rows_per_branch * p.n == rows, "layer norm: %d rows over %d branches of %d",
+              rows, p.n, p.rows_per_branch);
+    ln_fwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(x, p, y, stats, rows, d, eps);
     MPO_LAUNCH_CHECK();
     return 0;
+}
+int mpo_launch_ln_bwd_br(const float* dy, const float* x, const float* stats, const LnBranches& p, float* dx, int rows, int d,
+                         int accumulate, int what, hipStream_t s) {
+    if (rows <= 0 || !(what & 3)) return 0;
+    MPO_CHECK(p.n >= 1 && p.n <= kMaxBranches && p.rows_per_branch * p.n == rows, "layer norm: %d rows over %d branches of %d",
+              rows, p.n, p.rows_per_branch);
+    const int blocks = ((what & 1) ? (rows + 3) / 4 : 0) + ((what & 2) ? p.n * ((d + 15) / 16) : 0);
+    ln_bwd_kernel<<<blocks, 256, 0, s>>>(dy, x, stats, p, dx, rows, d, accumulate, what);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+static LnBranches one_branch(const float* w, const float* b, float* dw, float* db, int rows) {
+    LnBranches p;
+    p.n = 1; p.rows_per_branch = rows; p.w[0] = w; p.b[0] = b; p.dw[0] = dw; p.db[0] = db;
+    return p;
+}
+int mpo_launch_ln_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int rows, int d, float eps,
+                      hipStream_t s) {
+    return mpo_launch_ln_fwd_br(x, one_branch(w, b, nullptr, nullptr, rows), y, stats, rows, d, eps, s);
 }
 int mpo_launch_ln_bwd(const float* dy, const float* x, const float* stats, const float* w, float* dx, float* dw, float* db,
                       int rows, int d, int accumulate, hipStream_t s) {
-    if (rows <= 0) return 0;
-    if (dw) {
-        ln_bwd_params_kernel<<<(d + 15) / 16, 256, 0, s>>>(dy, x, stats, dw, db, rows, d);
-        MPO_LAUNCH_CHECK();
-    }
-    ln_bwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(dy, x, stats, w, dx, rows, d, accumulate);
-    MPO_LAUNCH_CHECK();
-    return 0;
+    return mpo_launch_ln_bwd_br(dy, x, stats, one_branch(w, nullptr, dw, db, rows), dx, rows, d, accumulate, dw ? 3 : 1, s);
 }
 int mpo_launch_ln_bwd_params_only(const float* dy, const float* x, const float* stats, float* dw, float* db, int rows, int d,
                                   hipStream_t s) {
-    ln_bwd_params_kernel<<<(d + 15) / 16, 256, 0, s>>>(dy, x, stats, dw, db, rows, d);
-    MPO_LAUNCH_CHECK();
-    return 0;
+    return mpo_launch_ln_bwd_br(dy, x, stats, one_branch(nullptr, nullptr, dw, db, rows), nullptr, rows, d, 0, 2, s);
 }
 int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, int T, int d, int H, float drop_p,
                              unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,

@@ -116,96 +116,149 @@ uint64_t mpo_encoder_rng_span(int n_slides, int T, int d, int ff, int layers) {
     return enc_stream_stride(n_slides, T, d, ff) * 4 * (uint64_t)layers;
 }
 
+// ---- branch batching: n_branches independent modules of IDENTICAL geometry (the path and the omic set-Transformer /
+// pooling head of one model) run as ONE launch sequence.  Activations are [branch][rows][width]; every GEMM becomes a
+// grouped launch with one member per branch; LayerNorm picks its parameters by row.  The dependent launch chain of
+// the token tail is latency-bound, so the second branch rides along for free.
+namespace {
+// dropout stream of branch br inside one stream slot: branches are rows_x_width elements apart
+inline DropSpec drop_br(DropSpec d, int br, size_t elems_per_branch) { d.off += (uint64_t)br * ((elems_per_branch + 3) / 4); return d; }
+inline GateSpec gate_rng_br(DropSpec d, int br, size_t elems_per_branch) { return gate_rng(drop_br(d, br, elems_per_branch)); }
+struct GroupBuilder {
+    GemmGroup g;
+    int add(const GemmArgs& a) {
+        if (g.n >= 8) { mpo_set_error("grouped gemm: more than 8 members"); return 1; }
+        g.g[g.n++] = a;
+        return 0;
+    }
+    int launch(hipStream_t s) { return g.n ? mpo_launch_gemm_mixed(g, s) : 0; }
+};
+}  // namespace
+
 // nn.TransformerEncoder (post-norm layers, ReLU FFN, no final norm): models/mcat/mcat.py:51-53,101-102;
 // layer arithmetic torch/nn/modules/transformer.py:661 (norm_first=False).
-int mpo_encoder_forward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
+int mpo_encoder_forward(const float* x, int n_branches, int n_slides, int T, int d, int ff, int heads, int layers,
                         const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                         float* y, float* saved, mpo_stream_t stream) {
     MPO_CHECK(n_slides >= 1 && layers >= 1 && d % heads == 0, "encoder: bad geometry (slides %d, layers %d, d %d, heads %d)",
               n_slides, layers, d, heads);
-    const int R = n_slides * T;
-    const uint64_t stride = enc_stream_stride(n_slides, T, d, ff);
+    MPO_CHECK(n_branches >= 1 && n_branches <= kMaxBranches, "encoder: 1..%d branches (got %d)", kMaxBranches, n_branches);
+    const int NB = n_branches, R = n_slides * T, RT = NB * R, BT = NB * n_slides;
+    const uint64_t stride = enc_stream_stride(BT, T, d, ff);
     Carver c(saved);
     const float* in = x;
     for (int l = 0; l < layers; ++l) {
-        const float* const* P = params + l * P_PER_LAYER;
         EncLayerSaved S;
-        enc_carve(c, &S, n_slides, T, d, ff, heads);
+        enc_carve(c, &S, BT, T, d, ff, heads);
         const uint64_t base = offset + stride * 4 * (uint64_t)l;
         const DropSpec d0 = stream_of(drop_p, seed, base, stride, 0, rng_epoch), d1 = stream_of(drop_p, seed, base, stride, 1, rng_epoch),
                        d2 = stream_of(drop_p, seed, base, stride, 2, rng_epoch), d3 = stream_of(drop_p, seed, base, stride, 3, rng_epoch);
-        RC(mpo_linear_fwd(in, P[P_INW], P[P_INB], S.qkv, R, d, 3 * d, 1.0f, MPO_ACT_NONE, stream));
-        RC(mpo_launch_mha_small_fwd(S.qkv, S.o, S.psave, n_slides, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, stream));
-        RC(mpo_linear_fwd(S.o, P[P_OUTW], P[P_OUTB], S.s1, R, d, d, 1.0f, MPO_ACT_NONE, stream, in, d1));
-        RC(mpo_launch_ln_fwd(S.s1, P[P_N1W], P[P_N1B], S.x1, S.st1, R, d, 1e-5f, stream));
-        RC(mpo_linear_fwd(S.x1, P[P_L1W], P[P_L1B], S.f, R, d, ff, 1.0f, MPO_ACT_RELU, stream, nullptr, d2));
-        RC(mpo_linear_fwd(S.f, P[P_L2W], P[P_L2B], S.s2, R, ff, d, 1.0f, MPO_ACT_NONE, stream, S.x1, d3));
         float* out = (l == layers - 1) ? y : S.x2;
-        RC(mpo_launch_ln_fwd(S.s2, P[P_N2W], P[P_N2B], out, S.st2, R, d, 1e-5f, stream));
+        auto P = [&](int br, int i) { return params[((size_t)br * layers + l) * P_PER_LAYER + i]; };
+        LnBranches n1, n2;
+        n1.n = n2.n = NB; n1.rows_per_branch = n2.rows_per_branch = R;
+        for (int br = 0; br < NB; ++br) { n1.w[br] = P(br, P_N1W); n1.b[br] = P(br, P_N1B); n2.w[br] = P(br, P_N2W); n2.b[br] = P(br, P_N2B); }
+        const size_t Rd = (size_t)R * d, Rf = (size_t)R * ff, Rq = (size_t)R * 3 * d;
+        GroupBuilder q, o, f1, f2;
+        for (int br = 0; br < NB; ++br) {
+            RC(q.add(mpo_args_fwd(in + br * Rd, P(br, P_INW), P(br, P_INB), S.qkv + br * Rq, R, d, 3 * d, 1.0f, MPO_ACT_NONE)));
+            RC(o.add(mpo_args_fwd(S.o + br * Rd, P(br, P_OUTW), P(br, P_OUTB), S.s1 + br * Rd, R, d, d, 1.0f, MPO_ACT_NONE,
+                                  in + br * Rd, drop_br(d1, br, Rd))));
+            RC(f1.add(mpo_args_fwd(S.x1 + br * Rd, P(br, P_L1W), P(br, P_L1B), S.f + br * Rf, R, d, ff, 1.0f, MPO_ACT_RELU, nullptr,
+                                   drop_br(d2, br, Rf))));
+            RC(f2.add(mpo_args_fwd(S.f + br * Rf, P(br, P_L2W), P(br, P_L2B), S.s2 + br * Rd, R, ff, d, 1.0f, MPO_ACT_NONE,
+                                   S.x1 + br * Rd, drop_br(d3, br, Rd))));
+        }
+        RC(q.launch(stream));
+        RC(mpo_launch_mha_small_fwd(S.qkv, S.o, S.psave, BT, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, stream));
+        RC(o.launch(stream));
+        RC(mpo_launch_ln_fwd_br(S.s1, n1, S.x1, S.st1, RT, d, 1e-5f, stream));
+        RC(f1.launch(stream));
+        RC(f2.launch(stream));
+        RC(mpo_launch_ln_fwd_br(S.s2, n2, out, S.st2, RT, d, 1e-5f, stream));
         in = out;
     }
     return 0;
 }
 
-int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int heads, int layers,
+int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, int d, int ff, int heads, int layers,
                          const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                          const float* saved, const float* dy, float* dx, float* const* grads, int phase,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
-    const int R = n_slides * T;
-    const uint64_t stride = enc_stream_stride(n_slides, T, d, ff);
+    MPO_CHECK(n_branches >= 1 && n_branches <= kMaxBranches, "encoder: 1..%d branches (got %d)", kMaxBranches, n_branches);
+    const int NB = n_branches, R = n_slides * T, RT = NB * R, BT = NB * n_slides;
+    const uint64_t stride = enc_stream_stride(BT, T, d, ff);
     MPO_CHECK(layers <= 8, "encoder: at most 8 layers (got %d)", layers);
     MPO_CHECK(phase >= 1 && phase <= 3, "backward phase must be 1, 2 or 3 (got %d)", phase);
     EncLayerSaved S[8];
     Carver c(const_cast<float*>(saved));
-    for (int l = 0; l < layers; ++l) enc_carve(c, &S[l], n_slides, T, d, ff, heads);
+    for (int l = 0; l < layers; ++l) enc_carve(c, &S[l], BT, T, d, ff, heads);
     Arena ws(workspace, workspace_bytes);
-    // The critical chain (LayerNorm / input-gradient GEMMs / attention) runs on the caller's stream; weight-gradient
-    // GEMMs and LayerNorm parameter reductions go to the side stream right after their inputs exist.  Nothing is
-    // updated in place and every layer has its own buffer set, so the side work only has to be joined at the end.
+    // phase 3: each layer's dx and dW products share one grouped launch.  Phases 1 / 2 split the critical data chain from
+    // the weight / LayerNorm-parameter gradients (nothing is updated in place, every layer has its own buffer set).
     SideSel side(stream, phase);
     const float* dcur = dy;
+    const size_t Rd = (size_t)R * d, Rf = (size_t)R * ff, Rq = (size_t)R * 3 * d;
     for (int l = layers - 1; l >= 0; --l) {
-        float* ds2 = ws.floats((size_t)R * d);
-        float* df = ws.floats((size_t)R * ff);
-        float* dx1 = ws.floats((size_t)R * d);
-        float* ds1 = ws.floats((size_t)R * d);
-        float* dob = ws.floats((size_t)R * d);
-        float* dqkv = ws.floats((size_t)R * 3 * d);
-        float* din = l == 0 ? dx : ws.floats((size_t)R * d);
+        float* ds2 = ws.floats((size_t)RT * d);
+        float* df = ws.floats((size_t)RT * ff);
+        float* dx1 = ws.floats((size_t)RT * d);
+        float* ds1 = ws.floats((size_t)RT * d);
+        float* dob = ws.floats((size_t)RT * d);
+        float* dqkv = ws.floats((size_t)RT * 3 * d);
+        float* din = l == 0 ? dx : ws.floats((size_t)RT * d);
         MPO_CHECK(ds2 && df && dx1 && ds1 && dob && dqkv && din, "encoder backward: workspace too small (%zu bytes)", workspace_bytes);
-        const float* const* P = params + l * P_PER_LAYER;
-        float* const* G = grads + l * P_PER_LAYER;
+        auto P = [&](int br, int i) { return params[((size_t)br * layers + l) * P_PER_LAYER + i]; };
+        auto G = [&](int br, int i) { return grads[((size_t)br * layers + l) * P_PER_LAYER + i]; };
         const float* in = l == 0 ? x : S[l - 1].x2;
         const uint64_t base = offset + stride * 4 * (uint64_t)l;
         const DropSpec d1 = stream_of(drop_p, seed, base, stride, 1, rng_epoch), d3 = stream_of(drop_p, seed, base, stride, 3, rng_epoch);
+        LnBranches n1, n2;
+        n1.n = n2.n = NB; n1.rows_per_branch = n2.rows_per_branch = R;
+        for (int br = 0; br < NB; ++br) {
+            n1.w[br] = P(br, P_N1W); n1.dw[br] = G(br, P_N1W); n1.db[br] = G(br, P_N1B);
+            n2.w[br] = P(br, P_N2W); n2.dw[br] = G(br, P_N2W); n2.db[br] = G(br, P_N2B);
+        }
+        // one grouped launch per product pair: members (dx_br, dW_br) for every branch
+        auto pairs = [&](auto&& mk_dx, auto&& mk_dw) -> int {
+            GroupBuilder main_g, side_g;
+            for (int br = 0; br < NB; ++br) {
+                if (phase & 1) RC(main_g.add(mk_dx(br)));
+                if (phase & 2) RC((phase == 3 ? main_g : side_g).add(mk_dw(br)));
+            }
+            RC(main_g.launch(stream));
+            if (side_g.g.n) RC(side_g.launch(side.get()));
+            return 0;
+        };
         // x2 = LN2(s2)
-        MAIN(mpo_launch_ln_bwd(dcur, S[l].s2, S[l].st2, P[P_N2W], ds2, nullptr, nullptr, R, d, 0, stream));
-        SIDE(mpo_launch_ln_bwd_params_only(dcur, S[l].s2, S[l].st2, G[P_N2W], G[P_N2B], R, d, side.get()));
+        RC(mpo_launch_ln_bwd_br(dcur, S[l].s2, S[l].st2, n2, ds2, RT, d, 0, phase, phase == 2 ? side.get() : stream));
         // s2 = x1 + drop3(f W2^T + b2)
-        PAIR(mpo_args_bwd_input(ds2, P[P_L2W], df, R, ff, d, 1.0f, 0, gate_rng(d3)),
-             mpo_args_bwd_weight(ds2, S[l].f, G[P_L2W], G[P_L2B], R, ff, d, 1.0f, gate_rng(d3)));
+        RC(pairs([&](int br) { return mpo_args_bwd_input(ds2 + br * Rd, P(br, P_L2W), df + br * Rf, R, ff, d, 1.0f, 0, gate_rng_br(d3, br, Rd)); },
+                 [&](int br) { return mpo_args_bwd_weight(ds2 + br * Rd, S[l].f + br * Rf, G(br, P_L2W), G(br, P_L2B), R, ff, d, 1.0f, gate_rng_br(d3, br, Rd)); }));
         // f = drop2(relu(x1 W1^T + b1));  dx1 = ds2 + (df*gate) W1
-        {
-            GemmArgs g;
-            g.A = df; g.B = P[P_L1W]; g.C = dx1; g.residual = ds2;
-            g.M = R; g.N = d; g.K = ff; g.lda = ff; g.ldb = d; g.ldc = d;
-            g.gate = S[l].f; g.gate_mode = MPO_GATE_RELU; g.gate_p = drop_p; g.layout = 2;
-            PAIR(g, mpo_args_bwd_weight(df, S[l].x1, G[P_L1W], G[P_L1B], R, d, ff, 1.0f, gate(S[l].f, MPO_GATE_RELU, drop_p)));
-        }
+        RC(pairs([&](int br) {
+                     GemmArgs g;
+                     g.A = df + br * Rf; g.B = P(br, P_L1W); g.C = dx1 + br * Rd; g.residual = ds2 + br * Rd;
+                     g.M = R; g.N = d; g.K = ff; g.lda = ff; g.ldb = d; g.ldc = d;
+                     g.gate = S[l].f + br * Rf; g.gate_mode = MPO_GATE_RELU; g.gate_p = drop_p; g.layout = 2;
+                     return g;
+                 },
+                 [&](int br) { return mpo_args_bwd_weight(df + br * Rf, S[l].x1 + br * Rd, G(br, P_L1W), G(br, P_L1B), R, d, ff, 1.0f,
+                                                          gate(S[l].f + br * Rf, MPO_GATE_RELU, drop_p)); }));
         // x1 = LN1(s1)
-        MAIN(mpo_launch_ln_bwd(dx1, S[l].s1, S[l].st1, P[P_N1W], ds1, nullptr, nullptr, R, d, 0, stream));
-        SIDE(mpo_launch_ln_bwd_params_only(dx1, S[l].s1, S[l].st1, G[P_N1W], G[P_N1B], R, d, side.get()));
+        RC(mpo_launch_ln_bwd_br(dx1, S[l].s1, S[l].st1, n1, ds1, RT, d, 0, phase, phase == 2 ? side.get() : stream));
         // s1 = in + drop1(o W_o^T + b_o)
-        PAIR(mpo_args_bwd_input(ds1, P[P_OUTW], dob, R, d, d, 1.0f, 0, gate_rng(d1)),
-             mpo_args_bwd_weight(ds1, S[l].o, G[P_OUTW], G[P_OUTB], R, d, d, 1.0f, gate_rng(d1)));
-        MAIN(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, n_slides, T, d, heads, stream));
+        RC(pairs([&](int br) { return mpo_args_bwd_input(ds1 + br * Rd, P(br, P_OUTW), dob + br * Rd, R, d, d, 1.0f, 0, gate_rng_br(d1, br, Rd)); },
+                 [&](int br) { return mpo_args_bwd_weight(ds1 + br * Rd, S[l].o + br * Rd, G(br, P_OUTW), G(br, P_OUTB), R, d, d, 1.0f, gate_rng_br(d1, br, Rd)); }));
+        MAIN(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, BT, T, d, heads, stream));
         // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in
-        {
-            GemmArgs g;
-            g.A = dqkv; g.B = P[P_INW]; g.C = din; g.residual = ds1;
-            g.M = R; g.N = d; g.K = 3 * d; g.lda = 3 * d; g.ldb = d; g.ldc = d; g.layout = 2;
-            PAIR(g, mpo_args_bwd_weight(dqkv, in, G[P_INW], G[P_INB], R, d, 3 * d, 1.0f));
-        }
+        RC(pairs([&](int br) {
+                     GemmArgs g;
+                     g.A = dqkv + br * Rq; g.B = P(br, P_INW); g.C = din + br * Rd; g.residual = ds1 + br * Rd;
+                     g.M = R; g.N = d; g.K = 3 * d; g.lda = 3 * d; g.ldb = d; g.ldc = d; g.layout = 2;
+                     return g;
+                 },
+                 [&](int br) { return mpo_args_bwd_weight(dqkv + br * Rq, in + br * Rd, G(br, P_INW), G(br, P_INB), R, d, 3 * d, 1.0f); }));
         dcur = din;
     }
     RC(side.join());
@@ -214,7 +267,7 @@ int mpo_encoder_backward(const float* x, int n_slides, int T, int d, int ff, int
 
 // ------------------------------------------------------------------------------------------- K5 gated pooling
 // params: attention_a.0.weight, .bias, attention_b.0.weight, .bias, attention_c.weight, .bias, rho.0.weight, .bias
-// saved: a [R,d] | b [R,d] | ab [R,d] | w [R] | hpool [B,d]
+// saved: a [R,d] | b [R,d] | ab [R,d] | w [R] | hpool [B,d]      (R, B over all branches)
 size_t mpo_gated_pool_saved_floats(int n_slides, int L, int d) {
     CarveSizer c;
     const size_t R = (size_t)n_slides * L;
@@ -227,67 +280,96 @@ size_t mpo_gated_pool_workspace_bytes(int n_slides, int L, int d) {
     s.floats((size_t)n_slides * d); s.floats(R); s.floats(R * d); s.floats(R * d); s.floats(R * d);
     return s.off + 256;
 }
-uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d) { return 3 * ((uint64_t)n_slides * L * d / 4 + 2); }
+uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d) { return 3 * ((uint64_t)n_slides * L * d / 4 + 2 + kMaxBranches); }
 
 // AttentionNetGated (models/blocks.py:13-48) + the pooling idiom of models/mcat/mcat.py:105-109:
 // scores = W_c[drop(tanh(W_a x)) * drop(sigmoid(W_b x))] + b_c; h = drop(relu(W_rho (softmax_L(scores) x) + b_rho))
-int mpo_gated_pool_forward(const float* x, int n_slides, int L, int d, const float* const* P,
+int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                            float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                            float* scores, float* h, float* saved, mpo_stream_t stream) {
-    const int R = n_slides * L;
-    const uint64_t stride = (uint64_t)R * d / 4 + 2;
+    MPO_CHECK(n_branches >= 1 && n_branches <= kMaxBranches, "gated pool: 1..%d branches (got %d)", kMaxBranches, n_branches);
+    const int NB = n_branches, R = n_slides * L, RT = NB * R, BT = NB * n_slides;
+    const uint64_t stride = (uint64_t)RT * d / 4 + 2 + kMaxBranches;
+    const size_t Rd = (size_t)R * d, Bd = (size_t)n_slides * d;
     Carver c(saved);
-    float* a = c.take((size_t)R * d); float* b = c.take((size_t)R * d); float* ab = c.take((size_t)R * d);
-    float* w = c.take(R); float* hpool = c.take((size_t)n_slides * d);
-    RC(mpo_gemm_together(stream,
-        mpo_args_fwd(x, P[0], P[1], a, R, d, d, 1.0f, MPO_ACT_TANH, nullptr, stream_of(head_drop_p, seed, offset, stride, 0, rng_epoch)),
-        mpo_args_fwd(x, P[2], P[3], b, R, d, d, 1.0f, MPO_ACT_SIGMOID, nullptr, stream_of(head_drop_p, seed, offset, stride, 1, rng_epoch))));
-    RC(mpo_launch_ew_mul(a, b, ab, R * d, stream));
-    RC(mpo_linear_fwd(ab, P[4], P[5], scores, R, d, 1, 1.0f, MPO_ACT_NONE, stream));
-    RC(mpo_launch_pool_fwd(scores, x, w, hpool, n_slides, L, d, stream));
-    RC(mpo_linear_fwd(hpool, P[6], P[7], h, n_slides, d, d, 1.0f, MPO_ACT_RELU, stream, nullptr, stream_of(rho_drop_p, seed, offset, stride, 2, rng_epoch)));
+    float* a = c.take((size_t)RT * d); float* b = c.take((size_t)RT * d); float* ab = c.take((size_t)RT * d);
+    float* w = c.take(RT); float* hpool = c.take((size_t)BT * d);
+    auto P = [&](int br, int i) { return params[br * 8 + i]; };
+    const DropSpec s0 = stream_of(head_drop_p, seed, offset, stride, 0, rng_epoch), s1 = stream_of(head_drop_p, seed, offset, stride, 1, rng_epoch),
+                   s2 = stream_of(rho_drop_p, seed, offset, stride, 2, rng_epoch);
+    GroupBuilder gab, gsc, grho;
+    for (int br = 0; br < NB; ++br) {
+        RC(gab.add(mpo_args_fwd(x + br * Rd, P(br, 0), P(br, 1), a + br * Rd, R, d, d, 1.0f, MPO_ACT_TANH, nullptr, drop_br(s0, br, Rd))));
+        RC(gab.add(mpo_args_fwd(x + br * Rd, P(br, 2), P(br, 3), b + br * Rd, R, d, d, 1.0f, MPO_ACT_SIGMOID, nullptr, drop_br(s1, br, Rd))));
+        RC(gsc.add(mpo_args_fwd(ab + br * Rd, P(br, 4), P(br, 5), scores + (size_t)br * R, R, d, 1, 1.0f, MPO_ACT_NONE)));
+        RC(grho.add(mpo_args_fwd(hpool + br * Bd, P(br, 6), P(br, 7), h + br * Bd, n_slides, d, d, 1.0f, MPO_ACT_RELU, nullptr,
+                                 drop_br(s2, br, Bd))));
+    }
+    RC(gab.launch(stream));
+    RC(mpo_launch_ew_mul(a, b, ab, RT * d, stream));
+    RC(gsc.launch(stream));
+    RC(mpo_launch_pool_fwd(scores, x, w, hpool, BT, L, d, stream));
+    RC(grho.launch(stream));
     return 0;
 }
 
-int mpo_gated_pool_backward(const float* x, int n_slides, int L, int d, const float* const* P,
+int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                             float head_drop_p, float rho_drop_p, const float* saved, const float* h,
-                            const float* dh, const float* d_scores_ext, float* dx, float* const* G, int phase,
+                            const float* dh, const float* d_scores_ext, float* dx, float* const* grads, int phase,
                             void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     MPO_CHECK(phase >= 1 && phase <= 3, "backward phase must be 1, 2 or 3 (got %d)", phase);
-    const int R = n_slides * L;
+    MPO_CHECK(n_branches >= 1 && n_branches <= 2, "gated pool backward: 1..2 branches (got %d)", n_branches);
+    const int NB = n_branches, R = n_slides * L, RT = NB * R, BT = NB * n_slides;
+    const size_t Rd = (size_t)R * d, Bd = (size_t)n_slides * d;
     Carver c(const_cast<float*>(saved));
-    const float* a = c.take((size_t)R * d); const float* b = c.take((size_t)R * d); const float* ab = c.take((size_t)R * d);
-    const float* w = c.take(R); const float* hpool = c.take((size_t)n_slides * d);
+    const float* a = c.take((size_t)RT * d); const float* b = c.take((size_t)RT * d); const float* ab = c.take((size_t)RT * d);
+    const float* w = c.take(RT); const float* hpool = c.take((size_t)BT * d);
     Arena ws(workspace, workspace_bytes);
-    float* dhpool = ws.floats((size_t)n_slides * d);
-    float* dscores = ws.floats(R);
-    float* dab = ws.floats((size_t)R * d);
-    float* da = ws.floats((size_t)R * d);
-    float* db = ws.floats((size_t)R * d);
+    float* dhpool = ws.floats((size_t)BT * d);
+    float* dscores = ws.floats(RT);
+    float* dab = ws.floats((size_t)RT * d);
+    float* da = ws.floats((size_t)RT * d);
+    float* db = ws.floats((size_t)RT * d);
     MPO_CHECK(dhpool && dscores && dab && da && db, "gated pool backward: workspace too small (%zu bytes)", workspace_bytes);
+    auto P = [&](int br, int i) { return params[br * 8 + i]; };
+    auto G = [&](int br, int i) { return grads[br * 8 + i]; };
     SideSel side(stream, phase);                            // weight gradients beside the dx chain (no buffer is rewritten)
+    auto pairs = [&](auto&& mk_dx, auto&& mk_dw) -> int {
+        GroupBuilder main_g, side_g;
+        for (int br = 0; br < NB; ++br) {
+            if (phase & 1) RC(main_g.add(mk_dx(br)));
+            if (phase & 2) RC((phase == 3 ? main_g : side_g).add(mk_dw(br)));
+        }
+        RC(main_g.launch(stream));
+        if (side_g.g.n) RC(side_g.launch(side.get()));
+        return 0;
+    };
     // h = drop(relu(hpool W_rho^T + b_rho))
-    PAIR(mpo_args_bwd_input(dh, P[6], dhpool, n_slides, d, d, 1.0f, 0, gate(h, MPO_GATE_RELU, rho_drop_p)),
-         mpo_args_bwd_weight(dh, hpool, G[6], G[7], n_slides, d, d, 1.0f, gate(h, MPO_GATE_RELU, rho_drop_p)));
-    MAIN(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, n_slides, L, d, stream));
+    RC(pairs([&](int br) { return mpo_args_bwd_input(dh + br * Bd, P(br, 6), dhpool + br * Bd, n_slides, d, d, 1.0f, 0, gate(h + br * Bd, MPO_GATE_RELU, rho_drop_p)); },
+             [&](int br) { return mpo_args_bwd_weight(dh + br * Bd, hpool + br * Bd, G(br, 6), G(br, 7), n_slides, d, d, 1.0f, gate(h + br * Bd, MPO_GATE_RELU, rho_drop_p)); }));
+    MAIN(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, BT, L, d, stream));
     // scores = ab W_c^T + b_c
-    PAIR(mpo_args_bwd_input(dscores, P[4], dab, R, d, 1, 1.0f, 0), mpo_args_bwd_weight(dscores, ab, G[4], G[5], R, d, 1, 1.0f));
-    MAIN(mpo_launch_ew_mul2(dab, b, a, da, db, R * d, stream));                  // da = dab * b,  db = dab * a
-    const GemmArgs dxa = mpo_args_bwd_input(da, P[0], dx, R, d, d, 1.0f, 1, gate(a, MPO_GATE_TANH, head_drop_p));
-    const GemmArgs dxb = mpo_args_bwd_input(db, P[2], dx, R, d, d, 1.0f, 1, gate(b, MPO_GATE_SIGMOID, head_drop_p));
-    const GemmArgs dwa = mpo_args_bwd_weight(da, x, G[0], G[1], R, d, d, 1.0f, gate(a, MPO_GATE_TANH, head_drop_p));
-    const GemmArgs dwb = mpo_args_bwd_weight(db, x, G[2], G[3], R, d, d, 1.0f, gate(b, MPO_GATE_SIGMOID, head_drop_p));
-    if (phase == 3) {                                       // dx accumulates twice: the second product follows alone
-        GemmGroup grp;
-        grp.g[0] = dxa; grp.g[1] = dwa; grp.g[2] = dwb; grp.n = 3;
-        RC(mpo_launch_gemm_mixed(grp, stream));
-        RC(mpo_launch_gemm(dxb, 1, 0, stream));
-    } else {
-        hipStream_t ss = side.get();
-        SIDE(mpo_launch_gemm(dwa, 0, 0, ss));
-        SIDE(mpo_launch_gemm(dwb, 0, 0, ss));
-        MAIN(mpo_launch_gemm(dxa, 1, 0, stream));
-        MAIN(mpo_launch_gemm(dxb, 1, 0, stream));
+    RC(pairs([&](int br) { return mpo_args_bwd_input(dscores + (size_t)br * R, P(br, 4), dab + br * Rd, R, d, 1, 1.0f, 0); },
+             [&](int br) { return mpo_args_bwd_weight(dscores + (size_t)br * R, ab + br * Rd, G(br, 4), G(br, 5), R, d, 1, 1.0f); }));
+    MAIN(mpo_launch_ew_mul2(dab, b, a, da, db, RT * d, stream));                 // da = dab * b,  db = dab * a
+    // a = drop(tanh(x W_a^T + b_a)), b = drop(sigmoid(x W_b^T + b_b)): dx accumulates both products, the second follows alone
+    {
+        GroupBuilder first, second, side_g;
+        for (int br = 0; br < NB; ++br) {
+            const GateSpec ga = gate(a + br * Rd, MPO_GATE_TANH, head_drop_p), gb = gate(b + br * Rd, MPO_GATE_SIGMOID, head_drop_p);
+            if (phase & 1) {
+                RC(first.add(mpo_args_bwd_input(da + br * Rd, P(br, 0), dx + br * Rd, R, d, d, 1.0f, 1, ga)));
+                RC(second.add(mpo_args_bwd_input(db + br * Rd, P(br, 2), dx + br * Rd, R, d, d, 1.0f, 1, gb)));
+            }
+            if (phase & 2) {
+                GroupBuilder& wg = phase == 3 ? first : side_g;
+                RC(wg.add(mpo_args_bwd_weight(da + br * Rd, x + br * Rd, G(br, 0), G(br, 1), R, d, d, 1.0f, ga)));
+                RC(wg.add(mpo_args_bwd_weight(db + br * Rd, x + br * Rd, G(br, 2), G(br, 3), R, d, d, 1.0f, gb)));
+            }
+        }
+        RC(first.launch(stream));
+        RC(second.launch(stream));
+        if (side_g.g.n) RC(side_g.launch(side.get()));
     }
     RC(side.join());
     return 0;

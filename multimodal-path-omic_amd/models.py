@@ -97,6 +97,18 @@ class _FusionModelBase(nn.Module):
         step is host-bound and this buys nothing; inside a captured graph (harness.GraphedWindowStep) the two
         chains really overlap."""
         g_bag = self._omic_fc(omics)
+        if self.batch_branches:
+            # the path and the omic set-Transformer / pooling head have identical geometry: run them as ONE launch
+            # sequence with grouped GEMMs.  The token tail is a latency-bound chain of small launches, so the omic
+            # branch rides along for free (no second stream, nothing to overlap by luck).
+            h_bags = self._patch_fc(bags)
+            h_coattn, a_coattn = self._co_attend(g_bag, h_bags, inference)
+            path, omic = ops.encoder_branches([h_coattn, g_bag], [list(self.path_transformer.layers), list(self.omic_transformer.layers)],
+                                              self.training)
+            (a_path, h_path), (a_omic, h_omic) = ops.gated_pool_branches(
+                [path, omic], [self.path_attention_head, self.omic_attention_head], [self.path_rho, self.omic_rho], self.training)
+            hazards, survs, y = ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
+            return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
         fork = self.fork_omic_branch and g_bag.is_cuda
         if fork:
             main = torch.cuda.current_stream(g_bag.device)
@@ -117,6 +129,7 @@ class _FusionModelBase(nn.Module):
         return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
 
     fork_omic_branch = not bool(os.environ.get("MPO_NO_FORK"))
+    batch_branches = not bool(os.environ.get("MPO_NO_BRANCH_BATCH"))     # A/B switch: fall back to two chains (+ fork)
 
     def _side_stream(self, device):
         st = getattr(self, "_side", None)

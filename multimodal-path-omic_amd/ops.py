@@ -404,19 +404,20 @@ def contextual_gate(q, q_hat, cag):
 
 
 class EncoderFn(torch.autograd.Function):
-    """K4: the whole post-norm nn.TransformerEncoder over (n_slides, T, d) tokens."""
+    """K4: the whole post-norm nn.TransformerEncoder over (n_slides, T, d) tokens; `branches` encoders of identical
+    geometry (x stacked branch-major, params branch-major) go through ONE launch sequence."""
 
     @staticmethod
     def forward(ctx, x, geom, drop_p, *params):
         lib = L.lib()
-        n_slides, T, d, ff, heads, layers = geom
+        branches, n_slides, T, d, ff, heads, layers = geom
         x = x.contiguous()
         y = torch.empty_like(x)
-        saved = torch.empty(lib.mpo_encoder_saved_floats(n_slides, T, d, ff, heads, layers), device=x.device,
+        saved = torch.empty(lib.mpo_encoder_saved_floats(branches * n_slides, T, d, ff, heads, layers), device=x.device,
                             dtype=torch.float32)
-        seed, off = _reserve(lib.mpo_encoder_rng_span(n_slides, T, d, ff, layers)) if drop_p > 0 else (0, 0)
+        seed, off = _reserve(lib.mpo_encoder_rng_span(branches * n_slides, T, d, ff, layers)) if drop_p > 0 else (0, 0)
         pa = L.ptr_array(params)
-        L.check(lib.mpo_encoder_forward(L.ptr(x), n_slides, T, d, ff, heads, layers, pa, float(drop_p), seed, off,
+        L.check(lib.mpo_encoder_forward(L.ptr(x), branches, n_slides, T, d, ff, heads, layers, pa, float(drop_p), seed, off,
                                         _epoch(), L.ptr(y), L.ptr(saved), L.stream_of(x)), "mpo_encoder_forward")
         ctx.save_for_backward(x, saved, *params)
         ctx.param_refs = params
@@ -427,33 +428,53 @@ class EncoderFn(torch.autograd.Function):
     def backward(ctx, dy):
         lib = L.lib()
         x, saved, *params = ctx.saved_tensors
-        n_slides, T, d, ff, heads, layers = ctx.geom
+        branches, n_slides, T, d, ff, heads, layers = ctx.geom
         drop_p, seed, off = ctx.drop
         dx = torch.empty_like(x)
         grads = [grad_out(p) for p in ctx.param_refs]
-        ws = _workspace(lib.mpo_encoder_workspace_bytes(n_slides, T, d, ff), x.device)
+        ws = _workspace(lib.mpo_encoder_workspace_bytes(branches * n_slides, T, d, ff), x.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         dy = dy.contiguous()
         _two_phase(lambda ph: L.check(lib.mpo_encoder_backward(
-            L.ptr(x), n_slides, T, d, ff, heads, layers, pa, drop_p, seed, off, _epoch(), L.ptr(saved), L.ptr(dy),
+            L.ptr(x), branches, n_slides, T, d, ff, heads, layers, pa, drop_p, seed, off, _epoch(), L.ptr(saved), L.ptr(dy),
             L.ptr(dx), ga, ph, L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_encoder_backward"), ws, x.device, ctx.param_refs, grads)
         for t in (dy, saved, x):
             _keep_for_side(t)
         return (dx, None, None, *grads)
 
 
-def encoder(x, layers, training: bool):
-    """x (B, T, d) through a stack of nn.TransformerEncoderLayer parameter holders."""
-    b, t, d = x.shape
-    l0 = layers[0]
+def _encoder_params(layers):
     params = []
     for ly in layers:
         params += [ly.self_attn.in_proj_weight, ly.self_attn.in_proj_bias, ly.self_attn.out_proj.weight,
                    ly.self_attn.out_proj.bias, ly.linear1.weight, ly.linear1.bias, ly.linear2.weight, ly.linear2.bias,
                    ly.norm1.weight, ly.norm1.bias, ly.norm2.weight, ly.norm2.bias]
-    geom = (b, t, d, l0.linear1.out_features, l0.self_attn.num_heads, len(layers))
-    y = EncoderFn.apply(x.reshape(b * t, d), geom, l0.dropout.p if training else 0.0, *params)
-    return y.view(b, t, d)
+    return params
+
+
+def _encoder_geom(layers):
+    l0 = layers[0]
+    return (l0.linear1.in_features, l0.linear1.out_features, l0.self_attn.num_heads, len(layers), l0.dropout.p)
+
+
+def encoder(x, layers, training: bool):
+    """x (B, T, d) through a stack of nn.TransformerEncoderLayer parameter holders."""
+    return encoder_branches([x], [layers], training)[0]
+
+
+def encoder_branches(xs, layer_stacks, training: bool):
+    """Several encoders of identical geometry (MCAT's path_transformer and omic_transformer) on inputs of identical
+    shape (B, T, d), batched into one launch sequence.  Returns one (B, T, d) tensor per branch."""
+    b, t, d = xs[0].shape
+    g0 = _encoder_geom(layer_stacks[0])
+    if any(x.shape != xs[0].shape for x in xs) or any(_encoder_geom(ls) != g0 for ls in layer_stacks):
+        raise ValueError("branch-batched encoders need identical input shapes and layer geometry")
+    nb = len(xs)
+    params = [p for ls in layer_stacks for p in _encoder_params(ls)]
+    x = xs[0].reshape(b * t, d) if nb == 1 else torch.cat([v.reshape(b * t, d) for v in xs], 0)
+    geom = (nb, b, t, d, g0[1], g0[2], g0[3])
+    y = EncoderFn.apply(x, geom, g0[4] if training else 0.0, *params)
+    return list(y.view(nb, b, t, d).unbind(0))
 
 
 class GatedPoolFn(torch.autograd.Function):
@@ -462,14 +483,15 @@ class GatedPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, geom, head_p, rho_p, *params):
         lib = L.lib()
-        n_slides, Lr, d = geom
+        branches, n_slides, Lr, d = geom
+        bt = branches * n_slides
         x = x.contiguous()
-        scores = torch.empty(n_slides * Lr, device=x.device, dtype=torch.float32)
-        h = torch.empty(n_slides, d, device=x.device, dtype=torch.float32)
-        saved = torch.empty(lib.mpo_gated_pool_saved_floats(n_slides, Lr, d), device=x.device, dtype=torch.float32)
-        seed, off = _reserve(lib.mpo_gated_pool_rng_span(n_slides, Lr, d)) if (head_p > 0 or rho_p > 0) else (0, 0)
+        scores = torch.empty(bt * Lr, device=x.device, dtype=torch.float32)
+        h = torch.empty(bt, d, device=x.device, dtype=torch.float32)
+        saved = torch.empty(lib.mpo_gated_pool_saved_floats(bt, Lr, d), device=x.device, dtype=torch.float32)
+        seed, off = _reserve(lib.mpo_gated_pool_rng_span(bt, Lr, d)) if (head_p > 0 or rho_p > 0) else (0, 0)
         pa = L.ptr_array(params)
-        L.check(lib.mpo_gated_pool_forward(L.ptr(x), n_slides, Lr, d, pa, float(head_p), float(rho_p), seed, off,
+        L.check(lib.mpo_gated_pool_forward(L.ptr(x), branches, n_slides, Lr, d, pa, float(head_p), float(rho_p), seed, off,
                                            _epoch(), L.ptr(scores), L.ptr(h), L.ptr(saved), L.stream_of(x)),
                 "mpo_gated_pool_forward")
         ctx.save_for_backward(x, saved, h, *params)
@@ -481,18 +503,18 @@ class GatedPoolFn(torch.autograd.Function):
     def backward(ctx, d_scores, dh):
         lib = L.lib()
         x, saved, h, *params = ctx.saved_tensors
-        n_slides, Lr, d = ctx.geom
+        branches, n_slides, Lr, d = ctx.geom
         head_p, rho_p = ctx.drop
         dx = torch.empty_like(x)
         grads = [grad_out(p) for p in ctx.param_refs]
         if dh is None:
             dh = torch.zeros_like(h)
-        ws = _workspace(lib.mpo_gated_pool_workspace_bytes(n_slides, Lr, d), x.device)
+        ws = _workspace(lib.mpo_gated_pool_workspace_bytes(branches * n_slides, Lr, d), x.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         dh = dh.contiguous()
         d_sc = d_scores.contiguous() if d_scores is not None else None
         _two_phase(lambda ph: L.check(lib.mpo_gated_pool_backward(
-            L.ptr(x), n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h), L.ptr(dh), L.ptr(d_sc), L.ptr(dx), ga, ph,
+            L.ptr(x), branches, n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h), L.ptr(dh), L.ptr(d_sc), L.ptr(dx), ga, ph,
             L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_gated_pool_backward"), ws, x.device, ctx.param_refs, grads)
         for t in (dh, saved, x, h):
             _keep_for_side(t)
@@ -501,14 +523,27 @@ class GatedPoolFn(torch.autograd.Function):
 
 def gated_pool(tokens, head, rho, training: bool):
     """tokens (B, L, d) -> raw scores (B, 1, L), pooled embedding (B, d)   (models/mcat/mcat.py:105-109)."""
-    b, l, d = tokens.shape
-    if head.attention_c.weight.shape[0] != 1 or head.attention_a[0].weight.shape != (d, d):
-        raise NotImplementedError("gated pooling kernel: n_classes=1 and hidden_dim == input_dim only")
-    params = (head.attention_a[0].weight, head.attention_a[0].bias, head.attention_b[0].weight, head.attention_b[0].bias,
-              head.attention_c.weight, head.attention_c.bias, rho[0].weight, rho[0].bias)
-    scores, h = GatedPoolFn.apply(tokens.reshape(b * l, d), (b, l, d), head.drop_p if training else 0.0,
-                                  rho[2].p if training else 0.0, *params)
-    return scores.view(b, 1, l), h
+    return gated_pool_branches([tokens], [head], [rho], training)[0]
+
+
+def gated_pool_branches(tokens, heads, rhos, training: bool):
+    """Several pooling heads of identical geometry on token sets of identical shape (B, L, d) -- the model's
+    path / omic attention heads + rho -- in one launch sequence.  Returns [(scores (B,1,L), h (B,d))] per branch."""
+    b, l, d = tokens[0].shape
+    nb = len(tokens)
+    params = []
+    for head, rho in zip(heads, rhos):
+        if head.attention_c.weight.shape[0] != 1 or head.attention_a[0].weight.shape != (d, d):
+            raise NotImplementedError("gated pooling kernel: n_classes=1 and hidden_dim == input_dim only")
+        params += [head.attention_a[0].weight, head.attention_a[0].bias, head.attention_b[0].weight, head.attention_b[0].bias,
+                   head.attention_c.weight, head.attention_c.bias, rho[0].weight, rho[0].bias]
+    if any(t.shape != tokens[0].shape for t in tokens) or len({(h.drop_p, r[2].p) for h, r in zip(heads, rhos)}) != 1:
+        raise ValueError("branch-batched pooling needs identical token shapes and dropout rates")
+    x = tokens[0].reshape(b * l, d) if nb == 1 else torch.cat([t.reshape(b * l, d) for t in tokens], 0)
+    scores, h = GatedPoolFn.apply(x, (nb, b, l, d), heads[0].drop_p if training else 0.0,
+                                  rhos[0][2].p if training else 0.0, *params)
+    scores, h = scores.view(nb, b, 1, l), h.view(nb, b, d)
+    return [(scores[i], h[i]) for i in range(nb)]
 
 
 class OmicSnnFn(torch.autograd.Function):
