@@ -316,8 +316,10 @@ __device__ __forceinline__ f32x4 direct_frag(const float* __restrict__ p, int ld
     }
     return r;
 }
+// gate factors for the four elements of one fragment; gv holds the gate tensor's values there (loaded WITH the
+// fragment, so the gate never adds a dependent memory round trip)
 template <bool KC>
-__device__ __forceinline__ void direct_gate(f32x4& v, const GateFn& gf, int ld, int mn, int mn_lim, int k0, int k_lim) {
+__device__ __forceinline__ void direct_gate(f32x4& v, const f32x4& gv, const GateFn& gf, int ld, int mn, int mn_lim, int k0, int k_lim) {
     if (mn >= mn_lim || k0 >= k_lim) return;
     if (KC) {
         const size_t idx0 = (size_t)mn * ld + k0;
@@ -326,19 +328,14 @@ __device__ __forceinline__ void direct_gate(f32x4& v, const GateFn& gf, int ld, 
             const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf.with_word(gf.g ? gf.g[idx0 + j] : 0.f, w[j]);
+            for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf.with_word(gv[j], w[j]);
             return;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf(gf.g ? gf.g[idx0 + j] : 0.f, idx0 + j);
+        for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf(gv[j], idx0 + j);
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (k0 + j < k_lim) {
-                const size_t idx = (size_t)(k0 + j) * ld + mn;
-                v[j] *= gf(gf.g ? gf.g[idx] : 0.f, idx);
-            }
-        }
+        for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf(gv[j], (size_t)(k0 + j) * ld + mn);
     }
 }
 
@@ -352,16 +349,19 @@ struct DirectCtx {
     bool a_vec, b_vec, gated, want_bsum;
     template <int NB>
     __device__ __forceinline__ void chunk(int kbase, f32x4& acc0, f32x4& acc1, float& bsum) const {
-        f32x4 a[NB], b[NB];
+        f32x4 a[NB], b[NB], gv[NB];
+        const bool gate_tensor = gated && gf.g != nullptr;
+        const bool g_vec = a_vec && (reinterpret_cast<uintptr_t>(gf.g) & 15) == 0;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int k0 = kbase + 16 * u + 4 * kq;
             a[u] = direct_frag<A_KC>(g.A, g.lda, m, g.M, k0, kend, a_vec);
             b[u] = direct_frag<B_KC>(g.B, g.ldb, n, g.N, k0, kend, b_vec);
+            gv[u] = gate_tensor ? direct_frag<A_KC>(gf.g, g.lda, m, g.M, k0, kend, g_vec) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            if (gated) direct_gate<A_KC>(a[u], gf, g.lda, m, g.M, kbase + 16 * u + 4 * kq, kend);
+            if (gated) direct_gate<A_KC>(a[u], gv[u], gf, g.lda, m, g.M, kbase + 16 * u + 4 * kq, kend);
             if (want_bsum) bsum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0], b[u][0], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1], b[u][1], acc1, 0, 0, 0);

@@ -72,8 +72,21 @@ def train_window(model, bags: BagBatch, omics, labels, cens, grad_acc_step: int)
     hazards, survs, _, _ = model.forward_window(bags, omics)
     from . import ops
     per_slide, risk = ops.ces_loss(hazards, survs, labels, cens)              # one HIP launch each way
-    (per_slide.sum() / grad_acc_step).backward()
+    # d(sum(loss) / grad_acc_step) / d(loss_b) = 1 / grad_acc_step: hand it over as a cached constant instead of
+    # building the sum / div graph (five tiny launches per window)
+    per_slide.backward(_slide_weights(per_slide.numel(), grad_acc_step, per_slide.device))
     return per_slide.detach(), risk
+
+
+_slide_weight_cache = {}
+
+
+def _slide_weights(n: int, grad_acc_step: int, device) -> torch.Tensor:
+    key = (n, grad_acc_step, str(device))
+    w = _slide_weight_cache.get(key)
+    if w is None:
+        w = _slide_weight_cache[key] = torch.full((n,), 1.0 / grad_acc_step, device=device, dtype=torch.float32)
+    return w
 
 
 class GraphedWindowStep:

@@ -103,12 +103,13 @@ class _FusionModelBase(nn.Module):
             # branch rides along for free (no second stream, nothing to overlap by luck).
             h_bags = self._patch_fc(bags)
             h_coattn, a_coattn = self._co_attend(g_bag, h_bags, inference)
-            path, omic = ops.encoder_branches([h_coattn, g_bag], [list(self.path_transformer.layers), list(self.omic_transformer.layers)],
-                                              self.training)
-            (a_path, h_path), (a_omic, h_omic) = ops.gated_pool_branches(
-                [path, omic], [self.path_attention_head, self.omic_attention_head], [self.path_rho, self.omic_rho], self.training)
-            hazards, survs, y = ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
-            return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
+            tokens = ops.encoder_stacked(torch.stack([h_coattn, g_bag]),
+                                         [list(self.path_transformer.layers), list(self.omic_transformer.layers)], self.training)
+            a, h = ops.gated_pool_stacked(tokens, [self.path_attention_head, self.omic_attention_head],
+                                          [self.path_rho, self.omic_rho], self.training)
+            hcat = h.transpose(0, 1).reshape(h.shape[1], -1)                  # (B, [h_path | h_omic]): one copy each way
+            hazards, survs, y = ops.fusion_head_cat(hcat, self.fusion_layer, self.classifier)
+            return hazards, survs, y, {"coattn": a_coattn, "path": a[0], "omic": a[1]}
         fork = self.fork_omic_branch and g_bag.is_cuda
         if fork:
             main = torch.cuda.current_stream(g_bag.device)

@@ -465,16 +465,23 @@ def encoder(x, layers, training: bool):
 def encoder_branches(xs, layer_stacks, training: bool):
     """Several encoders of identical geometry (MCAT's path_transformer and omic_transformer) on inputs of identical
     shape (B, T, d), batched into one launch sequence.  Returns one (B, T, d) tensor per branch."""
-    b, t, d = xs[0].shape
+    if len(xs) == 1:
+        return [encoder_stacked(xs[0].unsqueeze(0), layer_stacks, training)[0]]
+    if any(x.shape != xs[0].shape for x in xs):
+        raise ValueError("branch-batched encoders need identical input shapes")
+    return list(encoder_stacked(torch.stack(list(xs)), layer_stacks, training).unbind(0))
+
+
+def encoder_stacked(x, layer_stacks, training: bool):
+    """x (branches, B, T, d) -> (branches, B, T, d): branch i goes through layer_stacks[i]."""
+    nb, b, t, d = x.shape
     g0 = _encoder_geom(layer_stacks[0])
-    if any(x.shape != xs[0].shape for x in xs) or any(_encoder_geom(ls) != g0 for ls in layer_stacks):
-        raise ValueError("branch-batched encoders need identical input shapes and layer geometry")
-    nb = len(xs)
+    if len(layer_stacks) != nb or any(_encoder_geom(ls) != g0 for ls in layer_stacks) or g0[0] != d:
+        raise ValueError("branch-batched encoders need one layer stack per branch, all of identical geometry")
     params = [p for ls in layer_stacks for p in _encoder_params(ls)]
-    x = xs[0].reshape(b * t, d) if nb == 1 else torch.cat([v.reshape(b * t, d) for v in xs], 0)
     geom = (nb, b, t, d, g0[1], g0[2], g0[3])
-    y = EncoderFn.apply(x, geom, g0[4] if training else 0.0, *params)
-    return list(y.view(nb, b, t, d).unbind(0))
+    y = EncoderFn.apply(x.reshape(nb * b * t, d), geom, g0[4] if training else 0.0, *params)
+    return y.view(nb, b, t, d)
 
 
 class GatedPoolFn(torch.autograd.Function):
@@ -529,21 +536,29 @@ def gated_pool(tokens, head, rho, training: bool):
 def gated_pool_branches(tokens, heads, rhos, training: bool):
     """Several pooling heads of identical geometry on token sets of identical shape (B, L, d) -- the model's
     path / omic attention heads + rho -- in one launch sequence.  Returns [(scores (B,1,L), h (B,d))] per branch."""
-    b, l, d = tokens[0].shape
-    nb = len(tokens)
+    if len(tokens) == 1:
+        sc, h = gated_pool_stacked(tokens[0].unsqueeze(0), heads, rhos, training)
+        return [(sc[0], h[0])]
+    if any(t.shape != tokens[0].shape for t in tokens):
+        raise ValueError("branch-batched pooling needs identical token shapes")
+    sc, h = gated_pool_stacked(torch.stack(list(tokens)), heads, rhos, training)
+    return list(zip(sc.unbind(0), h.unbind(0)))
+
+
+def gated_pool_stacked(tokens, heads, rhos, training: bool):
+    """tokens (branches, B, L, d) -> raw scores (branches, B, 1, L), pooled embeddings (branches, B, d)."""
+    nb, b, l, d = tokens.shape
     params = []
     for head, rho in zip(heads, rhos):
         if head.attention_c.weight.shape[0] != 1 or head.attention_a[0].weight.shape != (d, d):
             raise NotImplementedError("gated pooling kernel: n_classes=1 and hidden_dim == input_dim only")
         params += [head.attention_a[0].weight, head.attention_a[0].bias, head.attention_b[0].weight, head.attention_b[0].bias,
                    head.attention_c.weight, head.attention_c.bias, rho[0].weight, rho[0].bias]
-    if any(t.shape != tokens[0].shape for t in tokens) or len({(h.drop_p, r[2].p) for h, r in zip(heads, rhos)}) != 1:
-        raise ValueError("branch-batched pooling needs identical token shapes and dropout rates")
-    x = tokens[0].reshape(b * l, d) if nb == 1 else torch.cat([t.reshape(b * l, d) for t in tokens], 0)
-    scores, h = GatedPoolFn.apply(x, (nb, b, l, d), heads[0].drop_p if training else 0.0,
+    if len(heads) != nb or len(rhos) != nb or len({(h.drop_p, r[2].p) for h, r in zip(heads, rhos)}) != 1:
+        raise ValueError("branch-batched pooling needs one head + rho per branch with identical dropout rates")
+    scores, h = GatedPoolFn.apply(tokens.reshape(nb * b * l, d), (nb, b, l, d), heads[0].drop_p if training else 0.0,
                                   rhos[0][2].p if training else 0.0, *params)
-    scores, h = scores.view(nb, b, 1, l), h.view(nb, b, d)
-    return [(scores[i], h[i]) for i in range(nb)]
+    return scores.view(nb, b, 1, l), h.view(nb, b, d)
 
 
 class OmicSnnFn(torch.autograd.Function):
@@ -677,9 +692,14 @@ class FusionHeadFn(torch.autograd.Function):
 
 def fusion_head(h_path, h_omic, fusion_layer, classifier):
     """(B,d),(B,d) -> hazards, survs, Y (B, C)   (models/fusion.py:17-19 + models/mcat/mcat.py:126-138)."""
+    return fusion_head_cat(torch.cat([h_path, h_omic], dim=-1), fusion_layer, classifier)
+
+
+def fusion_head_cat(hcat, fusion_layer, classifier):
+    """hcat (B, 2d) = [h_path | h_omic] already concatenated."""
     seq = fusion_layer.fusion_layer
-    return FusionHeadFn.apply(torch.cat([h_path, h_omic], dim=-1), seq[0].weight, seq[0].bias, seq[2].weight,
-                              seq[2].bias, classifier.weight, classifier.bias)
+    return FusionHeadFn.apply(hcat, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, classifier.weight,
+                              classifier.bias)
 
 
 # ------------------------------------------------------------------------------------ K2
