@@ -299,7 +299,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, GemmLds& lds) {
 //   * one LDS exchange at the end sums the four partial tiles; thread t then owns output element t.
 // Measured r01 in a HIP graph: 192x256x256 6.8 us (staged) -> see DESIGN.md.
 constexpr int DB = 16;                 // tile edge
-constexpr int DMAXB = 12;              // k-blocks (of 16) a wave keeps in flight
+constexpr int DMAXB = 8;               // k-blocks (of 16) a wave keeps in flight at most (12 made the compiler serialise the loads)
 
 template <bool KC>
 __device__ __forceinline__ f32x4 direct_frag(const float* __restrict__ p, int ld, int mn, int mn_lim, int k0, int k_lim, bool vec_ok) {
@@ -338,6 +338,30 @@ __device__ __forceinline__ void direct_gate(f32x4& v, const f32x4& gv, const Gat
         for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf(gv[j], (size_t)(k0 + j) * ld + mn);
     }
 }
+// Row-contiguous operand with a drawing gate: element (k0 + j, mn) has index (k0 + j) * ld + mn, so the four lanes of
+// a quad (mn = 4q .. 4q+3) share ONE Philox counter per j.  Lane s of the quad draws the counter of j = s and the
+// quad transposes the 4 x 4 words with four quad shuffles: one draw per lane and fragment instead of four.
+// Every lane of the wave must call this (no early exit before the shuffles).
+__device__ __forceinline__ void direct_gate_rows_quad(f32x4& v, const f32x4& gv, const GateFn& gf, int ld, int mn, int mn_lim,
+                                                      int k0, int k_lim, int lane) {
+    const int lq = lane & 3;
+    const size_t idx_own = (size_t)(k0 + lq) * ld + (mn & ~3);           // first element of the quad's group for j = lq
+    const uint64_t ctr = gf.off + (idx_own >> 2);
+    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
+    const uint32_t own[4] = {r.x, r.y, r.z, r.w};
+    uint32_t w[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int pick = lq ^ t;                                         // word wanted by the lane this value goes to
+        const uint32_t send = pick == 0 ? own[0] : pick == 1 ? own[1] : pick == 2 ? own[2] : own[3];
+        const uint32_t got = (uint32_t)__shfl_xor((int)send, t);        // from lane lq ^ t: its word for lane lq
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j == (lq ^ t)) w[j] = got;       // that lane drew element j = lq ^ t
+    }
+    if (mn >= mn_lim) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf.with_word(gv[j], w[j]);
+}
 
 // NB k-blocks of one wave: every load is issued before the first MFMA (out-of-range fragments are zero-filled,
 // so the count can be a compile-time constant and nothing is predicated)
@@ -345,12 +369,13 @@ template <bool A_KC, bool B_KC>
 struct DirectCtx {
     const GemmArgs& g;
     const GateFn& gf;
-    int m, n, kq, kend;
+    int m, n, kq, kend, lane;
     bool a_vec, b_vec, gated, want_bsum;
     template <int NB>
     __device__ __forceinline__ void chunk(int kbase, f32x4& acc0, f32x4& acc1, float& bsum) const {
         f32x4 a[NB], b[NB], gv[NB];
         const bool gate_tensor = gated && gf.g != nullptr;
+        const bool quad_draw = gf.draws() && (g.lda & 3) == 0;           // (m0 is a multiple of 16: quads are aligned)
         const bool g_vec = a_vec && (reinterpret_cast<uintptr_t>(gf.g) & 15) == 0;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -361,7 +386,10 @@ struct DirectCtx {
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            if (gated) direct_gate<A_KC>(a[u], gv[u], gf, g.lda, m, g.M, kbase + 16 * u + 4 * kq, kend);
+            if (gated) {
+                if (!A_KC && quad_draw) direct_gate_rows_quad(a[u], gv[u], gf, g.lda, m, g.M, kbase + 16 * u + 4 * kq, kend, lane);
+                else direct_gate<A_KC>(a[u], gv[u], gf, g.lda, m, g.M, kbase + 16 * u + 4 * kq, kend);
+            }
             if (want_bsum) bsum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0], b[u][0], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1], b[u][1], acc1, 0, 0, 0);
@@ -376,7 +404,7 @@ struct DirectLds {
     float bsum[4][16];
 };
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int NBMAX>
 __device__ __forceinline__ void gemm_f32_direct_body(const GemmArgs& g, DirectLds& lds) {
     if ((int)blockIdx.y * DB >= g.M || (int)blockIdx.x * DB >= g.N) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -397,10 +425,10 @@ __device__ __forceinline__ void gemm_f32_direct_body(const GemmArgs& g, DirectLd
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     float bsum = 0.f;
     const int nkb_all = kw >> 4;                                // wave-uniform AND workgroup-uniform block count
-    DirectCtx<A_KC, B_KC> cx{g, gf, m0 + i16, n0 + i16, kq, kend, a_vec, b_vec, gated, want_bsum};
-    if (nkb_all <= 4) cx.template chunk<4>(kbeg, acc0, acc1, bsum);
-    else if (nkb_all <= 8) cx.template chunk<8>(kbeg, acc0, acc1, bsum);
-    else for (int kb0 = 0; kb0 < nkb; kb0 += DMAXB) cx.template chunk<DMAXB>(kbeg + 16 * kb0, acc0, acc1, bsum);
+    DirectCtx<A_KC, B_KC> cx{g, gf, m0 + i16, n0 + i16, kq, kend, lane, a_vec, b_vec, gated, want_bsum};
+    // NBMAX is picked by the host from the largest K of the launch (4: K <= 256, 8: K <= 512, else 12): the register
+    // footprint -- hence how many workgroups a CU holds -- follows the blocks kept in flight
+    for (int kb0 = 0; kb0 < nkb_all; kb0 += NBMAX) cx.template chunk<NBMAX>(kbeg + 16 * kb0, acc0, acc1, bsum);
     (void)nkb;
     // ---- exchange: lane holds D[row = 4*kq + r][col = i16]
 #pragma unroll
@@ -436,22 +464,41 @@ __device__ __forceinline__ void gemm_f32_direct_body(const GemmArgs& g, DirectLd
         g.bias_grad[m0 + tid] = (lds.bsum[0][tid] + lds.bsum[1][tid]) + (lds.bsum[2][tid] + lds.bsum[3][tid]);
 }
 
+template <int NBMAX>
 __global__ __launch_bounds__(256)
 void gemm_f32_direct_kernel(GemmGroup grp) {
     __shared__ DirectLds lds;
     const GemmArgs& g = grp.g[blockIdx.z];
     switch (g.layout) {
-        case 3: gemm_f32_direct_body<true, true>(g, lds); break;
-        case 2: gemm_f32_direct_body<true, false>(g, lds); break;
-        case 1: gemm_f32_direct_body<false, true>(g, lds); break;
-        default: gemm_f32_direct_body<false, false>(g, lds); break;
+        case 3: gemm_f32_direct_body<true, true, NBMAX>(g, lds); break;
+        case 2: gemm_f32_direct_body<true, false, NBMAX>(g, lds); break;
+        case 1: gemm_f32_direct_body<false, true, NBMAX>(g, lds); break;
+        default: gemm_f32_direct_body<false, false, NBMAX>(g, lds); break;
     }
 }
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int NBMAX>
 __global__ __launch_bounds__(256)
 void gemm_f32_direct_single_kernel(GemmArgs g) {
     __shared__ DirectLds lds;
-    gemm_f32_direct_body<A_KC, B_KC>(g, lds);
+    gemm_f32_direct_body<A_KC, B_KC, NBMAX>(g, lds);
+}
+inline int direct_nbmax(int k) { return k <= 256 ? 4 : k <= 512 ? 8 : DMAXB; }
+template <bool A_KC, bool B_KC>
+void launch_direct_single(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+    switch (direct_nbmax(g.K)) {
+        case 4: gemm_f32_direct_single_kernel<A_KC, B_KC, 4><<<grid, 256, 0, stream>>>(g); break;
+        case 8: gemm_f32_direct_single_kernel<A_KC, B_KC, 8><<<grid, 256, 0, stream>>>(g); break;
+        default: gemm_f32_direct_single_kernel<A_KC, B_KC, DMAXB><<<grid, 256, 0, stream>>>(g); break;
+    }
+}
+void launch_direct_group(const GemmGroup& grp, dim3 grid, hipStream_t stream) {
+    int kmax = 0;
+    for (int i = 0; i < grp.n; ++i) kmax = grp.g[i].K > kmax ? grp.g[i].K : kmax;
+    switch (direct_nbmax(kmax)) {
+        case 4: gemm_f32_direct_kernel<4><<<grid, 256, 0, stream>>>(grp); break;
+        case 8: gemm_f32_direct_kernel<8><<<grid, 256, 0, stream>>>(grp); break;
+        default: gemm_f32_direct_kernel<DMAXB><<<grid, 256, 0, stream>>>(grp); break;
+    }
 }
 
 // MPO_GEMM_STAGED=1 selects the LDS-staged kernels everywhere (A/B comparison, debugging)
@@ -483,10 +530,10 @@ int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream) {
     MPO_CHECK(g.K > 0, "gemm: K must be positive (got %d)", g.K);
     if (use_direct()) {
         dim3 dgrid((g.N + DB - 1) / DB, (g.M + DB - 1) / DB);
-        if (a_kc && b_kc) gemm_f32_direct_single_kernel<true, true><<<dgrid, 256, 0, stream>>>(g);
-        else if (a_kc && !b_kc) gemm_f32_direct_single_kernel<true, false><<<dgrid, 256, 0, stream>>>(g);
-        else if (!a_kc && b_kc) gemm_f32_direct_single_kernel<false, true><<<dgrid, 256, 0, stream>>>(g);
-        else gemm_f32_direct_single_kernel<false, false><<<dgrid, 256, 0, stream>>>(g);
+        if (a_kc && b_kc) launch_direct_single<true, true>(g, dgrid, stream);
+        else if (a_kc && !b_kc) launch_direct_single<true, false>(g, dgrid, stream);
+        else if (!a_kc && b_kc) launch_direct_single<false, true>(g, dgrid, stream);
+        else launch_direct_single<false, false>(g, dgrid, stream);
         MPO_LAUNCH_CHECK();
         return 0;
     }
@@ -512,7 +559,7 @@ int mpo_launch_gemm_group(const GemmGroup& grp, int a_kc, int b_kc, hipStream_t 
         GemmGroup tagged = grp;
         for (int i = 0; i < tagged.n; ++i) tagged.g[i].layout = 2 * (a_kc ? 1 : 0) + (b_kc ? 1 : 0);
         dim3 dgrid((nx + DB - 1) / DB, (mx + DB - 1) / DB, grp.n);
-        gemm_f32_direct_kernel<<<dgrid, 256, 0, stream>>>(tagged);
+        launch_direct_group(tagged, dgrid, stream);
         MPO_LAUNCH_CHECK();
         return 0;
     }
@@ -537,7 +584,7 @@ int mpo_launch_gemm_mixed(const GemmGroup& grp, hipStream_t stream) {
     if (mx <= 0 || nx <= 0) return 0;
     if (use_direct()) {
         dim3 dgrid((nx + DB - 1) / DB, (mx + DB - 1) / DB, grp.n);
-        gemm_f32_direct_kernel<<<dgrid, 256, 0, stream>>>(grp);
+        launch_direct_group(grp, dgrid, stream);
         MPO_LAUNCH_CHECK();
         return 0;
     }
