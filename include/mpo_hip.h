@@ -90,12 +90,14 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                              const float* in_proj_weight, const float* out_proj_weight,
                              const float* saved, const float* attn_map,
                              const float* d_out, const float* d_attn_map,
-                             float* d_query, void* d_bag,
+                             float* d_query, void* d_bag, float* d_bag_colsum /* nullable [embed] */,
                              float* d_in_proj_weight, float* d_in_proj_bias,
                              float* d_out_proj_weight, float* d_out_proj_bias,
                              float bag_relu_gate, const mpo_bag_plan* plan /* nullable */,
                              void* workspace, size_t workspace_bytes, mpo_stream_t stream);
-/* bag_relu_gate: 0, or 1/(1-p) when the (bf16) bag is H = dropout_p(relu(.)) as in models/mcat/mcat.py:24-29,87 and
+/* d_bag_colsum (nullable): receives the column sums of d_bag, accumulated while the rows are written -- with the gate
+ * below that is the bias gradient of the patch layer self.H, which otherwise costs a pass over the 480k x 256 d_bag.
+ * bag_relu_gate: 0, or 1/(1-p) when the (bf16) bag is H = dropout_p(relu(.)) as in models/mcat/mcat.py:24-29,87 and
  * the caller wants d_bag already multiplied by that epilogue's derivative (H > 0 ? 1/(1-p) : 0): the H tile is still
  * in LDS when dH is formed, which saves two passes over the bag gradient. */
 

@@ -41,7 +41,7 @@ _SIGNATURES = {
     "mpo_coattn_mcat_forward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                         _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
-                                         _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
+                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
     "mpo_prepare_device": (c_int, [c_int]),
     "mpo_colsum_bf16": (c_int, [_P, _P, ctypes.c_int64, c_int, _P]),
     "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),

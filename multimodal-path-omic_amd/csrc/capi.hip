@@ -139,7 +139,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 4; }
+int mpo_abi_version(void) { return 5; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -175,6 +175,7 @@ size_t mpo_coattn_workspace_bytes(int n_slides, int n_q, int embed, int max_rows
     for (int i = 0; i < 4; ++i) b = arena_need(b, R * embed);
     b = arena_need(b, R);
     b = arena_need(b, parts * n_q * embed);
+    b = arena_need(b, parts * embed);
     a = f > b ? f : b;
     return a + 256;
 }
@@ -227,8 +228,8 @@ int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_ro
 int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int total_rows,
                              int max_rows, const float* query, int n_q, int embed, const float* in_w,
                              const float* out_w, const float* saved, const float* attn_map, const float* d_out,
-                             const float* d_attn_map, float* d_query, void* d_bag, float* d_in_w, float* d_in_b,
-                             float* d_out_w, float* d_out_b, float bag_relu_gate, const mpo_bag_plan* plan_,
+                             const float* d_attn_map, float* d_query, void* d_bag, float* d_bag_colsum, float* d_in_w,
+                             float* d_in_b, float* d_out_w, float* d_out_b, float bag_relu_gate, const mpo_bag_plan* plan_,
                              void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(embed != 512, "coattn backward: embed_dim 512 ('big') is not built yet");
@@ -243,7 +244,9 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
     float* dq_pre = ws.floats((size_t)R * E);
     float* delta = ws.floats(R);
     float* part_dqk = ws.floats(plan_parts(plan) * n_q * E);
-    MPO_CHECK(dattn && dctx && dqk && dq_pre && delta && part_dqk, "coattn backward: workspace too small (%zu bytes)", workspace_bytes);
+    float* part_cs = d_bag_colsum ? ws.floats(plan_parts(plan) * E) : nullptr;
+    MPO_CHECK(dattn && dctx && dqk && dq_pre && delta && part_dqk && (part_cs || !d_bag_colsum),
+              "coattn backward: workspace too small (%zu bytes)", workspace_bytes);
     const float* qs = saved;
     const float* qk2 = qs + (size_t)R * E;
     const float* ctx = qk2 + (size_t)R * E;
@@ -267,8 +270,10 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
         if ((rc = mpo_launch_map_rowdot(attn_map, d_attn_map, cu_rows, delta, n_slides, n_q, 1, stream))) return rc;
     // the bag pass
     if ((rc = mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, E, qk2, lse2, dctx, delta, attn_map,
-                                    d_attn_map, d_bag, part_dqk, n_q, plan, bag_relu_gate, stream))) return rc;
+                                    d_attn_map, d_bag, part_dqk, part_cs, n_q, plan, bag_relu_gate, stream))) return rc;
     if ((rc = mpo_launch_coattn_bwd_reduce(part_dqk, dqk, n_slides, n_q, E, plan, stream))) return rc;
+    if (d_bag_colsum)
+        if ((rc = mpo_launch_colsum(part_cs, d_bag_colsum, (int)plan_parts(plan), E, E, 0, stream))) return rc;
     // qk = qs W_k :  dqs = dqk W_k^T (folded with the 1/sqrt(E) of qs = scale * (...)),  dW_k = qs^T dqk,  db_k = 0
     if ((rc = mpo_gemm_together(stream, mpo_args_fwd(dqk, w_k, nullptr, dq_pre, R, E, E, scale, MPO_ACT_NONE),
                                 mpo_args_bwd_weight(qs, dqk, d_in_w + (size_t)E * E, nullptr, R, E, E, 1.0f)))) return rc;
@@ -434,7 +439,7 @@ int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_row
     const BagPlan plan = make_plan(plan_, n_slides, max_rows);
     if (int rc = check_plan(plan, n_slides)) return rc;
     return mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, lse2, dctx, delta, nullptr,
-                                 d_attn_map, d_bag, part_dqk, n_q, plan, 0.f, stream);
+                                 d_attn_map, d_bag, part_dqk, nullptr, n_q, plan, 0.f, stream);
 }
 
 // ------------------------------------------------------------------------------------------- patch layer epilogue

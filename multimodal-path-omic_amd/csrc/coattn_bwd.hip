@@ -60,6 +60,7 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                        const float* __restrict__ da_map,   // nullable, ragged [n_q][M_b] per slide
                        void* __restrict__ dbag_,           // [total_rows][E], bag dtype
                        float* __restrict__ part_dqk,       // [n_slides][splits][n_q][E] (natural units)
+                       float* __restrict__ part_colsum,    // nullable [parts][E]: column sums of the dH rows written here
                        int n_q, BagPlan plan,
                        float relu_gate /* 0: off; else 1/(1-p): dH *= (H > 0 ? relu_gate : 0), bf16 bag only */) {
     using G = TileGeom<E_>;
@@ -125,6 +126,13 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 
     const char* slide = reinterpret_cast<const char*>(bag_) + (size_t)row_begin * E_ * EB;
     char* dslide = reinterpret_cast<char*>(dbag_) + (size_t)row_begin * E_ * EB;
+
+    // column sums of the emitted dH (= the bias gradient of the layer that produced the bag when the ReLU gate is on):
+    // in the copy-out loop a lane always handles the same 16-byte column chunk, so it keeps that chunk's sums
+    constexpr int CS_N = 16 / EB;                                 // elements per 16-byte chunk
+    float csum[CS_N];
+#pragma unroll
+    for (int j = 0; j < CS_N; ++j) csum[j] = 0.f;
 
     Stage<E_, F32BAG> st0;
     Stage<E_, F32BAG> st1;
@@ -234,8 +242,19 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                 const int ci = i * 64 + lane;
                 const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(thi + r * (E_ * EB) + ((cc ^ ((r & 7) << 1)) << 4));
-                if (r < nvalid)
+                if (r < nvalid) {
                     *reinterpret_cast<f32x4*>(dslide + ((size_t)(trow + r) * CH_PER_ROW + cc) * 16) = v;
+                    if (part_colsum != nullptr) {
+                        if constexpr (F32BAG) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) csum[j] += v[j];
+                        } else {
+                            const bf16x8 hv = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) csum[j] += (float)hv[j];
+                        }
+                    }
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -256,6 +275,28 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) a += reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[idx];
         part_dqk[pbase * n_q * E_ + idx] = a;
+    }
+    if (part_colsum != nullptr) {                                 // same exchange for the column sums
+        __syncthreads();
+        constexpr int CH_PER_ROW = E_ * EB / 16;
+        static_assert(CH_PER_ROW <= 64 && 64 % CH_PER_ROW == 0, "a lane must keep one column chunk across the copy-out");
+#pragma unroll
+        for (int o = CH_PER_ROW; o < 64; o <<= 1) {               // lanes l, l + CH_PER_ROW, ... share a chunk
+#pragma unroll
+            for (int j = 0; j < CS_N; ++j) csum[j] += __shfl_xor(csum[j], o);
+        }
+        float* wc = reinterpret_cast<float*>(thi);
+        if (lane < CH_PER_ROW) {
+#pragma unroll
+            for (int j = 0; j < CS_N; ++j) wc[(lane % CH_PER_ROW) * CS_N + j] = csum[j];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < E_; idx += WAVES * 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) a += reinterpret_cast<const float*>(lds + w * C::WAVE_LDS)[idx];
+            part_colsum[pbase * E_ + idx] = a;
+        }
     }
 }
 
@@ -316,7 +357,8 @@ __global__ void map_rowdot_kernel(const float* __restrict__ a_map, const float* 
 int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                           const float* qk2, const float* lse2, const float* dctx, const float* delta,
                           const float* a_map, const float* da_map,
-                          void* dbag, float* part_dqk, int n_q, const BagPlan& plan, float relu_gate, hipStream_t stream) {
+                          void* dbag, float* part_dqk, float* part_colsum, int n_q, const BagPlan& plan, float relu_gate,
+                          hipStream_t stream) {
     (void)n_slides;
     (void)a_map;
     MPO_CHECK(relu_gate == 0.f || !bag_f32, "coattn backward: the fused relu/dropout gate needs a bf16 bag");
@@ -325,10 +367,10 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
     case EV:                                                                                                 \
         if (bag_f32)                                                                                         \
             coattn_bwd_kernel<EV, true><<<grid, BwdCfg<EV, true>::WAVES * 64, 0, stream>>>(                  \
-                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, plan, relu_gate);           \
+                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, part_colsum, n_q, plan, relu_gate);  \
         else                                                                                                 \
             coattn_bwd_kernel<EV, false><<<grid, BwdCfg<EV, false>::WAVES * 64, 0, stream>>>(                \
-                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, n_q, plan, relu_gate);           \
+                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, part_colsum, n_q, plan, relu_gate);  \
         break;
     switch (embed) {
         MPO_BWD_CASE(128)

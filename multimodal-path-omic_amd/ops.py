@@ -246,14 +246,19 @@ class CoAttnMCATFn(torch.autograd.Function):
             d_map = d_map.contiguous()
         d_query = torch.empty_like(query)
         d_bag = torch.empty_like(bag_data)
+        # with the fused gate d_bag IS the patch layer's pre-activation gradient: its column sums (that layer's bias
+        # gradient) fall out of the kernel's copy-out loop and travel on the tensor to PatchFcFn.backward
+        colsum = torch.empty(E, device=dev, dtype=torch.float32) if ctx.bag_relu_gate != 0.0 else None
         d_in_w, d_in_b, d_out_w, d_out_b = (grad_out(p) for p in ctx.param_refs)
         ws = _workspace(lib.mpo_coattn_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows), dev)
         L.check(lib.mpo_coattn_mcat_backward(
             L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, batch.total_rows,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(out_w), L.ptr(saved), L.ptr(amap),
-            L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), L.ptr(d_bag), L.ptr(d_in_w), L.ptr(d_in_b),
+            L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), L.ptr(d_bag), L.ptr(colsum), L.ptr(d_in_w), L.ptr(d_in_b),
             L.ptr(d_out_w), L.ptr(d_out_b), ctx.bag_relu_gate, batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)),
             "mpo_coattn_mcat_backward")
+        if colsum is not None:
+            d_bag._mpo_colsum = colsum
         return d_query, d_bag, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None
 
 
@@ -262,6 +267,9 @@ def coattn_mcat(query, batch: BagBatch, in_w, in_b, out_w, out_b, need_weights: 
     bag_relu_gate = 1/(1-p) when the bag comes from patch_fc(..., pre_gated_grad=True): d_bag then already
     carries the ReLU/dropout derivative (see include/mpo_hip.h)."""
     return CoAttnMCATFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, need_weights, bag_relu_gate)
+
+
+stats = {"colsum_handoffs": 0}           # counters the tests read to make sure a fused path really ran
 
 
 # ------------------------------------------------------------------------------------ patch layer (row H2)
@@ -299,7 +307,12 @@ class PatchFcFn(torch.autograd.Function):
                                                     L.stream_of(g)), "mpo_patch_epilogue_backward")
         dw, db = (grad_out(p) for p in ctx.param_refs)
         _splitk_tn(g, x, dw)
-        _colsum_two_stage(g, db)
+        ready = getattr(dh, "_mpo_colsum", None) if ctx.pre_gated else None
+        if ready is not None and ready.shape == db.shape:
+            db.copy_(ready)                 # produced by the co-attention backward kernel while it wrote dh
+            stats["colsum_handoffs"] += 1
+        else:
+            _colsum_two_stage(g, db)
         return None, dw, db, None, None
 
 
