@@ -494,7 +494,10 @@ void launch_direct_single(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 void launch_direct_group(const GemmGroup& grp, dim3 grid, hipStream_t stream) {
     int kmax = 0;
     for (int i = 0; i < grp.n; ++i) kmax = grp.g[i].K > kmax ? grp.g[i].K : kmax;
-    switch (direct_nbmax(kmax)) {
+    // a launch that fills the chip several times over is throughput-bound: the 4-block variant's smaller register
+    // footprint (4 instead of 2 workgroups per CU) then beats having all of K in flight at once
+    const size_t wgs = (size_t)grid.x * grid.y * grid.z;
+    switch (wgs > 1024 ? 4 : direct_nbmax(kmax)) {
         case 4: gemm_f32_direct_kernel<4><<<grid, 256, 0, stream>>>(grp); break;
         case 8: gemm_f32_direct_kernel<8><<<grid, 256, 0, stream>>>(grp); break;
         default: gemm_f32_direct_kernel<DMAXB><<<grid, 256, 0, stream>>>(grp); break;
