@@ -25,7 +25,11 @@ struct BwdCfg {
     static constexpr int NT = F32BAG ? 2 : 1;
     static constexpr int WAVES = (F32BAG && E_ == 512) ? 2 : 4;
     static constexpr int WAVE_LDS = NT * TileGeom<E_>::TILEB;     // also holds the dH image (E*2*32 or E*4*32 bytes)
-    static constexpr int LDS_BYTES = WAVES * WAVE_LDS;
+    static constexpr int TILES_BYTES = WAVES * WAVE_LDS;
+    // the per-slide Z^T operand of the dH product lives in LDS (one copy per workgroup): as 64-128 registers per lane
+    // it pushed the kernel far past the register file (1000+ accvgpr spill moves per pass over the loop)
+    static constexpr int Z_BYTES = NT * TileGeom<E_>::DT * 64 * 16;
+    static constexpr int LDS_BYTES = TILES_BYTES + Z_BYTES;
 };
 
 // rows-on-lane orientation: out[pt][r] = sum_k x[4g + r][k] * tile[16pt + (lane&15)][k]
@@ -89,10 +93,9 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 
     // Z^T operand of the dH product, per 16-column tile t: lane (d = 16t + c16, g) element j:
     //   j < 4 : dctx[4g + j][d]          j >= 4 : qk_nat[4g + j - 4][d]      (zero for query rows >= n_q)
-    bf16x8 zh[G::DT];
-    bf16x8 zl[NT == 2 ? G::DT : 1];
-#pragma unroll
-    for (int t = 0; t < G::DT; ++t) {
+    // kept in LDS as [hi | lo][t][lane] 16-byte fragments; the waves build a quarter each
+    bf16x8* zbuf = reinterpret_cast<bf16x8*>(lds + C::TILES_BYTES);
+    for (int t = wave; t < G::DT; t += WAVES) {
         float z[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -104,9 +107,10 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
         }
         bf16x8 h, l;
         pack_hi_lo(z, h, l);
-        zh[t] = h;
-        if (NT == 2) zl[t] = l;
+        zbuf[t * 64 + lane] = h;
+        if (NT == 2) zbuf[(G::DT + t) * 64 + lane] = l;
     }
+    __syncthreads();
 
     // per-lane row constants in both orientations; +inf lse switches padded query rows off (A = 0)
     const float lse_q = c16 < n_q ? lse2[(size_t)b * n_q + c16] : INFINITY;
@@ -202,15 +206,17 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 
         // ---------------- dH^T[d][p] = Z^T W^T, written over the (now dead) tile image
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int row = 16 * pt + c16;
+        for (int t = 0; t < G::DT; ++t) {
+            const bf16x8 zh = zbuf[t * 64 + lane];
+            const bf16x8 zl = NT == 2 ? zbuf[(G::DT + t) * 64 + lane] : zh;
 #pragma unroll
-            for (int t = 0; t < G::DT; ++t) {
+            for (int pt = 0; pt < 2; ++pt) {
+                const int row = 16 * pt + c16;
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                o = mfma_bf16(zh[t], wph[pt], o);
+                o = mfma_bf16(zh, wph[pt], o);
                 if (NT == 2) {
-                    o = mfma_bf16(zh[t], wpl[pt], o);
-                    o = mfma_bf16(zl[t], wph[pt], o);
+                    o = mfma_bf16(zh, wpl[pt], o);
+                    o = mfma_bf16(zl, wph[pt], o);
                 }
                 // lane holds dH[row][16t + 4g .. +3]
                 if constexpr (!F32BAG) {
