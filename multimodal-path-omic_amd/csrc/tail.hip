@@ -119,8 +119,14 @@ void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, 
         const int h = it / (T * T), i = (it / T) % T, j = it % T;
         const float* qi = sq + i * 3 * d + h * hd;
         const float* kj = sq + j * 3 * d + d + h * hd;
+        // every (h, i, j) row starts on the same LDS bank (offsets are multiples of hd = 32 floats): walk the head
+        // dimension from a per-thread rotation so that the lanes of a wave hit different banks
+        const int rot = tid % hd;
         float s = 0.f;
-        for (int c = 0; c < hd; ++c) s += qi[c] * kj[c];
+        for (int c = 0; c < hd; ++c) {
+            const int cc = c + rot < hd ? c + rot : c + rot - hd;
+            s += qi[cc] * kj[cc];
+        }
         sp[it] = s * scale;
     }
     __syncthreads();
@@ -166,18 +172,28 @@ void mha_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict
     __syncthreads();
     const float* pb = p_save + (size_t)b * 2 * H * T * T;
     const float* ppb = pb + H * T * T;
+    // dP[h][i][j] = do[i] . v[j] over the head's columns: one thread per (h, i, j), bank-rotated as in the forward
+    float* sdp = sds + H * T * T;         // [H][T][T]
+    for (int it = tid; it < H * T * T; it += 256) {
+        const int h = it / (T * T), i = (it / T) % T, j = it % T;
+        const float* vj = sq + j * 3 * d + 2 * d + h * hd;
+        const float* doi = sdo + i * d + h * hd;
+        const int rot = tid % hd;
+        float a = 0.f;
+        for (int c = 0; c < hd; ++c) {
+            const int cc = c + rot < hd ? c + rot : c + rot - hd;
+            a += doi[cc] * vj[cc];
+        }
+        sdp[it] = a;
+    }
+    __syncthreads();
     for (int it = tid; it < H * T; it += 256) {
-        const int h = it / T, i = it % T;
         float dp[kMaxT];
         float delta = 0.f;
         for (int j = 0; j < T; ++j) {
-            const float* vj = sq + j * 3 * d + 2 * d + h * hd;
-            const float* doi = sdo + i * d + h * hd;
-            float a = 0.f;
-            for (int c = 0; c < hd; ++c) a += doi[c] * vj[c];
             const float p = pb[it * T + j];
             const float ks = p > 0.f ? ppb[it * T + j] / p : 0.f;
-            dp[j] = a * ks;
+            dp[j] = sdp[it * T + j] * ks;
             delta += p * dp[j];
         }
         for (int j = 0; j < T; ++j) sds[it * T + j] = pb[it * T + j] * (dp[j] - delta) * scale;
@@ -481,7 +497,7 @@ int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, i
 int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float* d_o, float* dqkv, int B, int T, int d, int H,
                              hipStream_t s) {
     MPO_CHECK(T >= 1 && T <= kMaxT && d % H == 0, "set-transformer attention: T=%d (max %d), d=%d, heads=%d", T, kMaxT, d, H);
-    const size_t lds = ((size_t)T * 4 * d + (size_t)H * T * T) * sizeof(float);
+    const size_t lds = ((size_t)T * 4 * d + (size_t)2 * H * T * T) * sizeof(float);
     mha_small_bwd_kernel<<<B, 256, lds, s>>>(qkv, p_save, d_o, dqkv, T, d, H);
     MPO_LAUNCH_CHECK();
     return 0;
