@@ -15,8 +15,8 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-for chunk in (4096, 8192, 16384, 32768, 65536):
-    print(chunk, f"{timeit(lambda: _splitk_tn(g, x, out, chunk)):.1f} us")
+for chunk in (2048, 3000, 3750, 4096, 5000, 7500, 8192, 15000, 16384, 32768):
+    print(chunk, "rows/chunk ->", T // max(1, T // chunk), "x", max(1, T // chunk), f"{timeit(lambda: _splitk_tn(g, x, out, chunk)):.1f} us", flush=True)
 db = torch.empty(256, device=dev)
 print("bias sum", f"{timeit(lambda: torch.sum(g, 0, dtype=torch.float32, out=db)):.1f} us")
 ones = torch.ones(1, T, device=dev, dtype=torch.bfloat16)
