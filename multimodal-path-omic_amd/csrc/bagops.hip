@@ -416,21 +416,24 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
                             const float* __restrict__ z1, const float* __restrict__ w2, const float* __restrict__ z2,
                             void* __restrict__ dk, int n_q, BagPlan plan) {
     using G = TileGeom<E_>;
-    constexpr int IMG = kTileRows * E_ * 4;
+    constexpr int HR = 16;                                   // rows per step: half of a 32-row tile (one MFMA row block)
+    constexpr int IMG = HR * E_ * 4;
     constexpr int CH_PER_ROW = E_ / 4;
-    constexpr int NCH = kTileRows * CH_PER_ROW / 64;         // float4 per lane per tile (32 for E = 256)
-    __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
+    constexpr int NCH = HR * CH_PER_ROW / 64;                // float4 per lane per step (16 for E = 256)
+    // LDS: one fp32 half-tile image per wave + the per-slide Z fragments (hi/lo of both products), shared by the
+    // waves.  As registers (256 per lane) the Z fragments left no room to prefetch the next K rows.
+    constexpr int ZB = G::DT * 64 * 16;                      // one fragment set: [t][lane] x 16 bytes
+    __shared__ __attribute__((aligned(16))) char lds[4 * IMG + 4 * ZB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const SplitGeom sg = split_geom<4>(cu, plan, wave);
     const int b = sg.b;
     char* img = lds + wave * IMG;
+    bf16x8* zb = reinterpret_cast<bf16x8*>(lds + 4 * IMG);   // [z1h | z1l | z2h | z2l][t][lane]
     const int c16 = lane & 15, g = lane >> 4;
     const float* z1b = z1 + (size_t)b * n_q * E_;
     const float* z2b = z2 + (size_t)b * n_q * E_;
-    bf16x8 z1h[G::DT], z1l[G::DT], z2h[G::DT], z2l[G::DT];
-#pragma unroll
-    for (int t = 0; t < G::DT; ++t) {
+    for (int t = wave; t < G::DT; t += 4) {
         float a[8], c[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -440,59 +443,79 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
             a[j] = z1b[qc * E_ + 16 * t + c16] * live;
             c[j] = z2b[qc * E_ + 16 * t + c16] * live;
         }
-        pack_hi_lo(a, z1h[t], z1l[t]);
-        pack_hi_lo(c, z2h[t], z2l[t]);
+        bf16x8 ah, al, ch, cl;
+        pack_hi_lo(a, ah, al);
+        pack_hi_lo(c, ch, cl);
+        zb[(0 * G::DT + t) * 64 + lane] = ah;
+        zb[(1 * G::DT + t) * 64 + lane] = al;
+        zb[(2 * G::DT + t) * 64 + lane] = ch;
+        zb[(3 * G::DT + t) * 64 + lane] = cl;
     }
+    __syncthreads();
     const float* w1b = w1 + (size_t)n_q * sg.row_begin;
     const float* w2b = w2 + (size_t)n_q * sg.row_begin;
     const float* kslide = kbag + (size_t)sg.row_begin * E_;
     char* dslide = reinterpret_cast<char*>(dk) + (size_t)sg.row_begin * E_ * (OUT_BF16 ? 2 : 4);
-    for (int it = 0; it < sg.n_my; ++it) {
-        const int trow = sg.r0 + kTileRows * (wave + it * 4);
-        const int nvalid = min(kTileRows, sg.r1 - trow);
+    // step st covers rows  tile(st >> 1) + 16 (st & 1);  the K rows of the NEXT step travel in registers meanwhile
+    auto step_row = [&](int st) { return sg.r0 + kTileRows * (wave + (st >> 1) * 4) + HR * (st & 1); };
+    f32x4 kv[NCH];
+    auto fetch = [&](int row0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = i * 64 + lane;
+            const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
+            int grow = row0 + r;
+            grow = grow < sg.m_rows ? grow : sg.m_rows - 1;
+            kv[i] = *reinterpret_cast<const f32x4*>(kslide + (size_t)grow * E_ + cc * 4);
+        }
+    };
+    const int n_steps = 2 * sg.n_my;
+    if (n_steps > 0) fetch(step_row(0));
+    for (int st = 0; st < n_steps; ++st) {
+        const int row0 = step_row(st);
+        const int nvalid = max(0, min(HR, sg.r1 - row0));
         // stage K (fp32) into the image, same chunk swizzle as the output image
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ci = i * 64 + lane;
             const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
-            int grow = trow + r;
-            grow = grow < sg.m_rows ? grow : sg.m_rows - 1;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(kslide + (size_t)grow * E_ + cc * 4);
-            *reinterpret_cast<f32x4*>(img + r * (E_ * 4) + ((cc ^ ((r & 7) << 1)) << 4)) = v;
+            *reinterpret_cast<f32x4*>(img + r * (E_ * 4) + ((cc ^ ((r & 7) << 1)) << 4)) = kv[i];
         }
+        if (st + 1 < n_steps) fetch(step_row(st + 1));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int row = 16 * pt + c16;
+        if (nvalid > 0) {
+            const int row = c16;
             const bool ok = row < nvalid;
             float wa[8], wb[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int qq = 4 * g + (j & 3);
                 const bool live = ok && qq < n_q && j < 4;
-                wa[j] = live ? w1b[(size_t)qq * sg.m_rows + trow + row] : 0.f;
-                wb[j] = live ? w2b[(size_t)qq * sg.m_rows + trow + row] : 0.f;
+                wa[j] = live ? w1b[(size_t)qq * sg.m_rows + row0 + row] : 0.f;
+                wb[j] = live ? w2b[(size_t)qq * sg.m_rows + row0 + row] : 0.f;
             }
             bf16x8 wah, wal, wbh, wbl;
             pack_hi_lo(wa, wah, wal);
             pack_hi_lo(wb, wbh, wbl);
 #pragma unroll
             for (int t = 0; t < G::DT; ++t) {
+                const bf16x8 z1h = zb[(0 * G::DT + t) * 64 + lane], z1l = zb[(1 * G::DT + t) * 64 + lane];
+                const bf16x8 z2h = zb[(2 * G::DT + t) * 64 + lane], z2l = zb[(3 * G::DT + t) * 64 + lane];
                 f32x4 o1 = {0.f, 0.f, 0.f, 0.f}, o2 = o1;
-                o1 = mfma_bf16(z1h[t], wah, o1);
-                o1 = mfma_bf16(z1h[t], wal, o1);
-                o1 = mfma_bf16(z1l[t], wah, o1);
-                o2 = mfma_bf16(z2h[t], wbh, o2);
-                o2 = mfma_bf16(z2h[t], wbl, o2);
-                o2 = mfma_bf16(z2l[t], wbh, o2);
+                o1 = mfma_bf16(z1h, wah, o1);
+                o1 = mfma_bf16(z1h, wal, o1);
+                o1 = mfma_bf16(z1l, wah, o1);
+                o2 = mfma_bf16(z2h, wbh, o2);
+                o2 = mfma_bf16(z2h, wbl, o2);
+                o2 = mfma_bf16(z2l, wbh, o2);
                 const int c = (4 * t + g) ^ ((row & 7) << 1);
                 f32x4* slot = reinterpret_cast<f32x4*>(img + row * (E_ * 4) + (c << 4));
-                const f32x4 kv = *slot;
+                const f32x4 kvs = *slot;
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float tk = fast_tanh(kv[j]);
+                    const float tk = fast_tanh(kvs[j]);
                     o[j] = o1[j] + o2[j] * (1.0f - tk * tk);
                 }
                 *slot = o;
@@ -508,9 +531,9 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
             if (r < nvalid) {
                 if constexpr (OUT_BF16) {
                     bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(dslide + ((size_t)(trow + r) * E_ + cc * 4) * 2) = o;
+                    *reinterpret_cast<bf16x4*>(dslide + ((size_t)(row0 + r) * E_ + cc * 4) * 2) = o;
                 } else {
-                    *reinterpret_cast<f32x4*>(dslide + ((size_t)(trow + r) * E_ + cc * 4) * 4) = v;
+                    *reinterpret_cast<f32x4*>(dslide + ((size_t)(row0 + r) * E_ + cc * 4) * 4) = v;
                 }
             }
         }
