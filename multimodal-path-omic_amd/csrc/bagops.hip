@@ -542,48 +542,124 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
 }
 
 // ------------------------------------------------------------------ map kernels (one workgroup per (query, slide))
+constexpr int kMapThreads = 512;                               // 8 waves per (query, slide) row
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < kMapThreads / 64; ++w) r = fmaxf(r, red[w]);
+    return r;
 }
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < kMapThreads / 64; ++w) r += red[w];
+    return r;
+}
+
+// The map kernels walk a (query, slide) row of the ragged map in ALIGNED GROUPS of four elements (absolute index
+// 4G .. 4G+3): one float4 access per array and ONE Philox draw per group (the dropout counter is index >> 2), with
+// the group's first/last elements masked at the row ends.  (Element-wise they drew one Philox per element: 53 / 106 us.)
+struct MapRow {
+    size_t base;       // absolute index of the row's first element
+    int m_rows;
+    size_t g0;         // first group
+    int n_groups;
+    __device__ __forceinline__ MapRow(const int* cu, int n_q, int q, int b) {
+        const int row_begin = cu[b];
+        m_rows = cu[b + 1] - row_begin;
+        base = (size_t)n_q * row_begin + (size_t)q * m_rows;
+        g0 = base >> 2;
+        n_groups = (int)(((base + m_rows + 3) >> 2) - g0);
+    }
+    // lanes of group G that belong to the row: bit j set <=> element 4G + j is inside
+    __device__ __forceinline__ unsigned live(size_t G) const {
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = 4 * G + j;
+            if (i >= base && i < base + m_rows) m |= 1u << j;
+        }
+        return m;
+    }
+};
+__device__ __forceinline__ f32x4 map_load4(const float* __restrict__ p, size_t G, unsigned live) {
+    if (live == 0xFu) return *reinterpret_cast<const f32x4*>(p + 4 * G);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (live >> j & 1) v[j] = p[4 * G + j];
+    return v;
+}
+__device__ __forceinline__ void map_store4(float* __restrict__ p, size_t G, unsigned live, const f32x4& v) {
+    if (live == 0xFu) { *reinterpret_cast<f32x4*>(p + 4 * G) = v; return; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (live >> j & 1) p[4 * G + j] = v[j];
+}
+// keep-scales of the four elements of group G (same draw as dropout_keep(seed, offset, 4G + j, ...))
+__device__ __forceinline__ f32x4 map_keep4(unsigned long long seed, unsigned long long offset, size_t G, float p, float inv_keep) {
+    const unsigned long long ctr = offset + G;
+    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    f32x4 k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = (float)(w[j] >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.0f;
+    return k;
 }
 
 // a: log2-unit half-logits (qs2.k), g: gate dot (tq.tk).  S2 = a (g + 1).
 // Writes lse2[b][q], the (post-dropout) map A_drop in place of `amap`, and asum[b][q] = sum_m A_drop.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kMapThreads)
 void gated_softmax_fwd_kernel(const float* __restrict__ amap_a, const float* __restrict__ gmap, const int* __restrict__ cu,
                               float* __restrict__ out_map, float* __restrict__ lse2, float* __restrict__ asum,
                               int n_q, float drop_p, unsigned long long seed, unsigned long long offset_,
                               const unsigned long long* epoch) {
-    __shared__ float red[4];
+    __shared__ float red[kMapThreads / 64];
     const unsigned long long offset = epoch_offset(offset_, epoch);
     const int q = blockIdx.x, b = blockIdx.y;
-    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
-    const size_t base = (size_t)n_q * row_begin + (size_t)q * m_rows;
+    const MapRow row(cu, n_q, q, b);
     float mx = -INFINITY;
-    for (int m = threadIdx.x; m < m_rows; m += 256) mx = fmaxf(mx, amap_a[base + m] * (gmap[base + m] + 1.0f));
+    for (int i = threadIdx.x; i < row.n_groups; i += kMapThreads) {
+        const size_t G = row.g0 + i;
+        const unsigned lv = row.live(G);
+        const f32x4 a = map_load4(amap_a, G, lv), g = map_load4(gmap, G, lv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (lv >> j & 1) mx = fmaxf(mx, a[j] * (g[j] + 1.0f));
+    }
     mx = block_max(mx, red);
     float l = 0.f;
-    for (int m = threadIdx.x; m < m_rows; m += 256)
-        l += __builtin_amdgcn_exp2f(amap_a[base + m] * (gmap[base + m] + 1.0f) - mx);
+    for (int i = threadIdx.x; i < row.n_groups; i += kMapThreads) {
+        const size_t G = row.g0 + i;
+        const unsigned lv = row.live(G);
+        const f32x4 a = map_load4(amap_a, G, lv), g = map_load4(gmap, G, lv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (lv >> j & 1) l += __builtin_amdgcn_exp2f(a[j] * (g[j] + 1.0f) - mx);
+    }
     l = block_sum(l, red);
     const float lse = mx + __builtin_amdgcn_logf(l);
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     float s = 0.f;
-    for (int m = threadIdx.x; m < m_rows; m += 256) {
-        float v = __builtin_amdgcn_exp2f(amap_a[base + m] * (gmap[base + m] + 1.0f) - lse);
-        if (drop_p > 0.f) v *= dropout_keep(seed, offset, base + m, drop_p, inv_keep);
-        out_map[base + m] = v;
-        s += v;
+    for (int i = threadIdx.x; i < row.n_groups; i += kMapThreads) {
+        const size_t G = row.g0 + i;
+        const unsigned lv = row.live(G);
+        const f32x4 a = map_load4(amap_a, G, lv), g = map_load4(gmap, G, lv);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(a[j] * (g[j] + 1.0f) - lse);
+        if (drop_p > 0.f) {
+            const f32x4 k = map_keep4(seed, offset, G, drop_p, inv_keep);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= k[j];
+        }
+        map_store4(out_map, G, lv, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (lv >> j & 1) s += v[j];
     }
     s = block_sum(s, red);
     if (threadIdx.x == 0) {
@@ -595,38 +671,51 @@ void gated_softmax_fwd_kernel(const float* __restrict__ amap_a, const float* __r
 // Backward of the gated softmax.  da_map holds dctx.H (from bag_rowdot) on entry; d_ext (nullable) is the
 // gradient arriving on the returned (post-dropout) map; dasum[b][q] the gradient of the row sums.
 // On exit: ds1_map[n][m] = dS (g+1)/2 (natural units, for q~.k) and dg_map[n][m] = dS * s1/2.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kMapThreads)
 void gated_softmax_bwd_kernel(const float* __restrict__ amap_a, const float* __restrict__ gmap, const int* __restrict__ cu,
                               const float* __restrict__ lse2, const float* __restrict__ dasum,
                               const float* __restrict__ d_ext, float* __restrict__ da_map /* in: dctx.H, out: ds1 */,
                               float* __restrict__ dg_map, int n_q, float drop_p, unsigned long long seed,
                               unsigned long long offset_, const unsigned long long* epoch) {
-    __shared__ float red[4];
+    __shared__ float red[kMapThreads / 64];
     const unsigned long long offset = epoch_offset(offset_, epoch);
     const int q = blockIdx.x, b = blockIdx.y;
-    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
-    const size_t base = (size_t)n_q * row_begin + (size_t)q * m_rows;
+    const MapRow row(cu, n_q, q, b);
     const float lse = lse2[(size_t)b * n_q + q];
     const float das = dasum[(size_t)b * n_q + q];
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     float delta = 0.f;
-    for (int m = threadIdx.x; m < m_rows; m += 256) {
-        const float a = __builtin_amdgcn_exp2f(amap_a[base + m] * (gmap[base + m] + 1.0f) - lse);
-        const float ks = drop_p > 0.f ? dropout_keep(seed, offset, base + m, drop_p, inv_keep) : 1.0f;
-        float d = da_map[base + m] + das;
-        if (d_ext) d += d_ext[base + m];
-        delta += a * ks * d;
+    for (int i = threadIdx.x; i < row.n_groups; i += kMapThreads) {
+        const size_t G = row.g0 + i;
+        const unsigned lv = row.live(G);
+        const f32x4 ah = map_load4(amap_a, G, lv), gg = map_load4(gmap, G, lv), dd = map_load4(da_map, G, lv);
+        const f32x4 de = d_ext ? map_load4(d_ext, G, lv) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 ks = drop_p > 0.f ? map_keep4(seed, offset, G, drop_p, inv_keep) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (lv >> j & 1) {
+                const float a = __builtin_amdgcn_exp2f(ah[j] * (gg[j] + 1.0f) - lse);
+                delta += a * ks[j] * (dd[j] + das + de[j]);
+            }
+        }
     }
     delta = block_sum(delta, red);
-    for (int m = threadIdx.x; m < m_rows; m += 256) {
-        const float ah = amap_a[base + m], gg = gmap[base + m];
-        const float a = __builtin_amdgcn_exp2f(ah * (gg + 1.0f) - lse);
-        const float ks = drop_p > 0.f ? dropout_keep(seed, offset, base + m, drop_p, inv_keep) : 1.0f;
-        float d = da_map[base + m] + das;
-        if (d_ext) d += d_ext[base + m];
-        const float ds = a * (ks * d - delta);
-        da_map[base + m] = ds * (gg + 1.0f) * 0.5f;      // d/d(q~.k)
-        dg_map[base + m] = ds * ah * kLn2;               // dS * s1/2 with s1/2 = ah / log2(e)
+    for (int i = threadIdx.x; i < row.n_groups; i += kMapThreads) {
+        const size_t G = row.g0 + i;
+        const unsigned lv = row.live(G);
+        const f32x4 ah = map_load4(amap_a, G, lv), gg = map_load4(gmap, G, lv), dd = map_load4(da_map, G, lv);
+        const f32x4 de = d_ext ? map_load4(d_ext, G, lv) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 ks = drop_p > 0.f ? map_keep4(seed, offset, G, drop_p, inv_keep) : f32x4{1.f, 1.f, 1.f, 1.f};
+        f32x4 o1, o2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = __builtin_amdgcn_exp2f(ah[j] * (gg[j] + 1.0f) - lse);
+            const float ds = a * (ks[j] * (dd[j] + das + de[j]) - delta);
+            o1[j] = ds * (gg[j] + 1.0f) * 0.5f;      // d/d(q~.k)
+            o2[j] = ds * ah[j] * kLn2;               // dS * s1/2 with s1/2 = ah / log2(e)
+        }
+        map_store4(da_map, G, lv, o1);
+        map_store4(dg_map, G, lv, o2);
     }
 }
 
@@ -895,7 +984,7 @@ int mpo_launch_bag_outer_gated(const float* kbag, const int* cu, int n_slides, i
 int mpo_launch_gated_softmax_fwd(const float* amap_a, const float* gmap, const int* cu, float* out_map, float* lse2,
                                  float* asum, int n_slides, int n_q, float drop_p, unsigned long long seed,
                                  unsigned long long offset, const unsigned long long* epoch, hipStream_t stream) {
-    gated_softmax_fwd_kernel<<<dim3(n_q, n_slides), 256, 0, stream>>>(amap_a, gmap, cu, out_map, lse2, asum, n_q, drop_p, seed, offset, epoch);
+    gated_softmax_fwd_kernel<<<dim3(n_q, n_slides), kMapThreads, 0, stream>>>(amap_a, gmap, cu, out_map, lse2, asum, n_q, drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }
@@ -904,7 +993,7 @@ int mpo_launch_gated_softmax_bwd(const float* amap_a, const float* gmap, const i
                                  const float* dasum, const float* d_ext, float* da_map, float* dg_map, int n_slides,
                                  int n_q, float drop_p, unsigned long long seed, unsigned long long offset,
                                  const unsigned long long* epoch, hipStream_t stream) {
-    gated_softmax_bwd_kernel<<<dim3(n_q, n_slides), 256, 0, stream>>>(amap_a, gmap, cu, lse2, dasum, d_ext, da_map, dg_map, n_q,
+    gated_softmax_bwd_kernel<<<dim3(n_q, n_slides), kMapThreads, 0, stream>>>(amap_a, gmap, cu, lse2, dasum, d_ext, da_map, dg_map, n_q,
                                                                       drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
