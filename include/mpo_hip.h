@@ -103,11 +103,13 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
 
 /* ---- epilogue of the patch layer self.H (models/mcat/mcat.py:24-29): h = dropout_p(relu(h + bias)) in place on the
  * bf16 GEMM output [rows, cols], and its derivative g = dy * (h > 0 ? 1/(1-p) : 0).  The GEMM itself stays a library
- * call. */
+ * call.  Backward: n = rows * cols elements; d_bias (nullable, [cols]) receives the column
+ * sums of g -- the layer's bias gradient -- from the same pass (workspace of *_workspace_bytes then required). */
 int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, int cols, float drop_p, uint64_t seed,
                                uint64_t offset, const uint64_t* rng_epoch, mpo_stream_t stream);
-int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, float drop_p,
-                                mpo_stream_t stream);
+size_t mpo_patch_epilogue_backward_workspace_bytes(int64_t n, int cols);
+int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, int cols, float drop_p,
+                                float* d_bias /* nullable */, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 /* out[c] = sum_r x[r][c] for a bf16 [rows, cols] tensor: the bias gradient of self.H (torch's reduce: 142 us) */
 int mpo_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, mpo_stream_t stream);
 
@@ -130,7 +132,8 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
  *   seed/offset Philox counter of the attention-weight dropout; pass the same pair to backward.
  * Backward takes gradients on all three returns (d_out, d_attn_map nullable, d_q_proj nullable) and emits
  * d_query, d_kbag (dk_dtype: a GRADIENT may be handed on in bf16), d_hbag (bag dtype) and the q / v / out-projection
- * gradients; the key slices of d_in_proj_* are zeroed (the caller back-propagates d_kbag through its GEMM). */
+ * gradients; the key slices of d_in_proj_* are zeroed (the caller back-propagates d_kbag through its GEMM).
+ * d_kbag_colsum (nullable) receives the column sums of d_kbag (= the key bias gradient) from the pass that writes it. */
 size_t mpo_nacagat_saved_floats(int n_slides, int n_q, int embed);
 size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_rows, int total_rows);
 int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,
@@ -148,7 +151,8 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                 float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
-                                float* d_query, void* d_kbag, int dk_dtype, void* d_hbag,
+                                float* d_query, void* d_kbag, int dk_dtype, float* d_kbag_colsum /* nullable [embed] */,
+                                void* d_hbag,
                                 float* d_in_proj_weight, float* d_in_proj_bias,
                                 float* d_out_proj_weight, float* d_out_proj_bias, const mpo_bag_plan* plan /* nullable */,
                                 void* workspace, size_t workspace_bytes, mpo_stream_t stream);

@@ -46,14 +46,15 @@ _SIGNATURES = {
     "mpo_colsum_bf16": (c_int, [_P, _P, ctypes.c_int64, c_int, _P]),
     "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     "mpo_patch_epilogue_forward": (c_int, [_P, _P, ctypes.c_int64, c_int, c_float, c_uint64, c_uint64, _P, _P]),
-    "mpo_patch_epilogue_backward": (c_int, [_P, _P, _P, ctypes.c_int64, c_float, _P]),
+    "mpo_patch_epilogue_backward_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int]),
+    "mpo_patch_epilogue_backward": (c_int, [_P, _P, _P, ctypes.c_int64, c_int, c_float, _P, _P, c_size_t, _P]),
     "mpo_nacagat_saved_floats": (c_size_t, [c_int, c_int, c_int]),
     "mpo_nacagat_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "mpo_coattn_nacagat_forward": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                            c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_nacagat_backward": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
                                             c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P,
-                                            _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                            _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_ces_loss_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P]),
     "mpo_ces_loss_backward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, c_int, _P, _P, _P]),
     "mpo_encoder_saved_floats": (c_size_t, [c_int] * 6),

@@ -414,7 +414,8 @@ template <int E_, bool OUT_BF16>
 __global__ __launch_bounds__(256, 1)
 void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restrict__ cu, const float* __restrict__ w1,
                             const float* __restrict__ z1, const float* __restrict__ w2, const float* __restrict__ z2,
-                            void* __restrict__ dk, int n_q, BagPlan plan) {
+                            void* __restrict__ dk, float* __restrict__ part_colsum /* nullable [parts][E] */, int n_q,
+                            BagPlan plan) {
     using G = TileGeom<E_>;
     constexpr int HR = 16;                                   // rows per step: half of a 32-row tile (one MFMA row block)
     constexpr int IMG = HR * E_ * 4;
@@ -470,6 +471,8 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
         }
     };
     const int n_steps = 2 * sg.n_my;
+    static_assert(CH_PER_ROW == 64, "copy-out: a lane keeps one 4-column chunk (E = 256)");
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};                       // column sums of the rows this lane copies out
     if (n_steps > 0) fetch(step_row(0));
     for (int st = 0; st < n_steps; ++st) {
         const int row0 = step_row(st);
@@ -532,12 +535,25 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
                 if constexpr (OUT_BF16) {
                     bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                     *reinterpret_cast<bf16x4*>(dslide + ((size_t)(row0 + r) * E_ + cc * 4) * 2) = o;
+                    csum += f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};      // what the caller will sum
                 } else {
                     *reinterpret_cast<f32x4*>(dslide + ((size_t)(row0 + r) * E_ + cc * 4) * 4) = v;
+                    csum += v;
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (part_colsum != nullptr) {
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(img + lane * 16) = csum;               // lane == column chunk
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < E_; idx += 256) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += reinterpret_cast<const float*>(lds + w * IMG)[idx];
+            part_colsum[(size_t)sg.part * E_ + idx] = a;
+        }
     }
 }
 
@@ -793,14 +809,37 @@ __global__ void bias_relu_dropout_bf16_kernel(bf16x8* __restrict__ h, const floa
         h[i] = v;
     }
 }
-__global__ void relu_dropout_bwd_bf16_kernel(const bf16x8* __restrict__ h, const bf16x8* __restrict__ dy, bf16x8* __restrict__ g,
-                                             size_t n8, float inv_keep) {
+// g = dy * (h > 0 ? 1/(1-p) : 0).  part_colsum (nullable, [gridDim.x][cols]): per-workgroup column sums of g -- the bias
+// gradient of the layer -- from the same pass (a thread keeps one 8-column group: the grid stride is a multiple of a row).
+__global__ __launch_bounds__(256)
+void relu_dropout_bwd_bf16_kernel(const bf16x8* __restrict__ h, const bf16x8* __restrict__ dy, bf16x8* __restrict__ g,
+                                  size_t n8, float inv_keep, int cols, float* __restrict__ part_colsum) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const bf16x8 hv = h[i], d = dy[i];
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (float)hv[j] > 0.f ? (__bf16)((float)d[j] * inv_keep) : (__bf16)0.f;
         g[i] = o;
+        if (part_colsum != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)o[j];
+        }
+    }
+    if (part_colsum != nullptr) {
+        __shared__ float red[256][9];
+        const int tpr = cols / 8, c8 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = 0.f;
+                for (int k = 0; k < 256 / tpr; ++k) t += red[k * tpr + c8][j];
+                part_colsum[(size_t)blockIdx.x * cols + 8 * c8 + j] = t;
+            }
+        }
     }
 }
 
@@ -883,12 +922,20 @@ int mpo_launch_bias_relu_dropout_bf16(void* h, const float* bias, size_t rows, i
     MPO_LAUNCH_CHECK();
     return 0;
 }
-int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, size_t n, float drop_p, hipStream_t stream) {
-    MPO_CHECK(n % 8 == 0, "patch epilogue backward: %zu elements not a multiple of 8", n);
+int mpo_relu_dropout_bwd_blocks(size_t n, int with_colsum) {
     const size_t n8 = n / 8;
-    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    const size_t cap = with_colsum ? 512 : 8192;           // column sums: fewer, longer workgroups (one partial row each)
+    return (int)((n8 + 255) / 256 < cap ? (n8 + 255) / 256 : cap);
+}
+int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, size_t n, float drop_p, int cols,
+                                     float* part_colsum /* nullable [blocks][cols] */, hipStream_t stream) {
+    MPO_CHECK(n % 8 == 0, "patch epilogue backward: %zu elements not a multiple of 8", n);
+    MPO_CHECK(!part_colsum || (cols >= 8 && cols % 8 == 0 && 256 % (cols / 8) == 0 && n % (size_t)cols == 0),
+              "patch epilogue backward: column sums need cols in {8,..,2048} dividing 2048 (got %d)", cols);
+    const size_t n8 = n / 8;
+    const int blocks = mpo_relu_dropout_bwd_blocks(n, part_colsum != nullptr);
     relu_dropout_bwd_bf16_kernel<<<blocks, 256, 0, stream>>>((const bf16x8*)h, (const bf16x8*)dy, (bf16x8*)g, n8,
-                                                             drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f);
+                                                             drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, cols, part_colsum);
     MPO_LAUNCH_CHECK();
     return 0;
 }
@@ -968,15 +1015,13 @@ int mpo_launch_bag_colacc_gated(const void* bag, int bag_f32, const int* cu, int
 }
 
 int mpo_launch_bag_outer_gated(const float* kbag, const int* cu, int n_slides, int embed, const float* w1, const float* z1,
-                               const float* w2, const float* z2, void* dk, int dk_f32, int n_q, const BagPlan& plan,
-                               hipStream_t stream) {
+                               const float* w2, const float* z2, void* dk, int dk_f32, float* part_colsum, int n_q,
+                               const BagPlan& plan, hipStream_t stream) {
     (void)n_slides;
+    MPO_CHECK(embed == 256, "gated outer-product pass: embed_dim %d not built (256 only)", embed);
     dim3 grid = plan_grid(plan);
-    if (dk_f32) {
-        MPO_E_SWITCH(embed, (bag_outer_gated_kernel<EV, false><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, n_q, plan)))
-    } else {
-        MPO_E_SWITCH(embed, (bag_outer_gated_kernel<EV, true><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, n_q, plan)))
-    }
+    if (dk_f32) bag_outer_gated_kernel<256, false><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, part_colsum, n_q, plan);
+    else bag_outer_gated_kernel<256, true><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, part_colsum, n_q, plan);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -139,7 +139,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 5; }
+int mpo_abi_version(void) { return 6; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -298,6 +298,7 @@ size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_row
     b = arena_need(b, R);
     b = arena_need(b, max_parts(n_slides) * n_q * embed);
     b = arena_need(b, max_parts(n_slides) * n_q * embed);
+    b = arena_need(b, max_parts(n_slides) * embed);
     b = arena_need(b, (size_t)n_q * total_rows);
     b = arena_need(b, (size_t)n_q * total_rows);
     return b + 256;
@@ -352,7 +353,7 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                 const float* out_w, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
-                                float* d_query, void* d_kbag, int dk_dtype, void* d_hbag,
+                                float* d_query, void* d_kbag, int dk_dtype, float* d_kbag_colsum, void* d_hbag,
                                 float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
                                 const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
@@ -372,6 +373,8 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     float* dasum = ws.floats(R);
     float* part = ws.floats(plan_parts(splits) * n_q * E);
     float* part2 = ws.floats(plan_parts(splits) * n_q * E);
+    float* part_cs = d_kbag_colsum ? ws.floats(plan_parts(splits) * E) : nullptr;
+    MPO_CHECK(part_cs || !d_kbag_colsum, "nacagat backward: workspace too small (%zu bytes)", workspace_bytes);
     float* ds1_map = ws.floats((size_t)n_q * total_rows);
     float* dg_map = ws.floats((size_t)n_q * total_rows);
     MPO_CHECK(dattn && dctx && dqt && dtq && dq && spare && dasum && part && part2 && ds1_map && dg_map,
@@ -416,11 +419,14 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     // bag side: dK = ds1^T q~ + (dg^T tq) * (1 - TK^2),  dH = A_drop^T dctx
     // (one pass: tanh' from the staged K tile)
     if ((rc = mpo_launch_bag_outer_gated(static_cast<const float*>(kbag), cu_rows, n_slides, E, ds1_map, qt, dg_map, tq,
-                                         d_kbag, dk_dtype == MPO_F32, n_q, splits, stream))) return rc;
+                                         d_kbag, dk_dtype == MPO_F32, part_cs, n_q, splits, stream))) return rc;
+    if (d_kbag_colsum)
+        if ((rc = mpo_launch_colsum(part_cs, d_kbag_colsum, (int)plan_parts(splits), E, E, 0, stream))) return rc;
     if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, attn_map, dctx, nullptr, nullptr, d_hbag, f32, n_q, splits, stream))) return rc;
     // the key slice of the packed in-projection belongs to the caller's K = H W_k^T + b_k
     MPO_HIP(hipMemsetAsync(d_in_w + (size_t)E * E, 0, (size_t)E * E * sizeof(float), stream));
-    MPO_HIP(hipMemsetAsync(d_in_b + E, 0, (size_t)E * sizeof(float), stream));
+    if (d_kbag_colsum != d_in_b + E)            // (a caller may have the key-bias gradient written straight into its slice)
+        MPO_HIP(hipMemsetAsync(d_in_b + E, 0, (size_t)E * sizeof(float), stream));
     return 0;
 }
 
@@ -451,9 +457,17 @@ int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, in
 int mpo_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, mpo_stream_t stream) {
     return mpo_launch_colsum_bf16(x_bf16, out, (size_t)rows, cols, stream);
 }
-int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, float drop_p,
-                                mpo_stream_t stream) {
-    return mpo_launch_relu_dropout_bwd_bf16(h_bf16, dy_bf16, g_bf16, (size_t)n, drop_p, stream);
+size_t mpo_patch_epilogue_backward_workspace_bytes(int64_t n, int cols) {
+    return (size_t)mpo_relu_dropout_bwd_blocks((size_t)n, 1) * (size_t)cols * sizeof(float) + 256;
+}
+int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g_bf16, int64_t n, int cols, float drop_p,
+                                float* d_bias, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    if (!d_bias) return mpo_launch_relu_dropout_bwd_bf16(h_bf16, dy_bf16, g_bf16, (size_t)n, drop_p, cols, nullptr, stream);
+    MPO_CHECK(workspace && workspace_bytes >= mpo_patch_epilogue_backward_workspace_bytes(n, cols),
+              "patch epilogue backward: workspace too small (%zu bytes)", workspace_bytes);
+    float* part = static_cast<float*>(workspace);
+    if (int rc = mpo_launch_relu_dropout_bwd_bf16(h_bf16, dy_bf16, g_bf16, (size_t)n, drop_p, cols, part, stream)) return rc;
+    return mpo_launch_colsum(part, d_bias, mpo_relu_dropout_bwd_blocks((size_t)n, 1), cols, cols, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------- optimiser

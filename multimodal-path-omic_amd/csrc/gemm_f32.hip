@@ -510,18 +510,22 @@ bool use_direct() {
     return v;
 }
 
-// colsum[n] (+)= sum_m X[m][n]   (bias gradients): 64 columns per workgroup, 4 waves split the rows
-__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int ld, int accumulate) {
-    __shared__ float red[4][64];
-    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + c;
+// colsum[n] (+)= sum_m X[m][n]   (bias gradients, merging per-workgroup partials): 16 columns per workgroup, 16 row
+// groups of 16 lanes (64 columns x 4 row groups left a [1024][256] merge on 4 workgroups: 62 us)
+__global__ __launch_bounds__(256)
+void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int ld, int accumulate) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
     float s = 0.f;
     if (n < N)
-        for (int m = w; m < M; m += 4) s += x[(size_t)m * ld + n];
-    red[w][c] = s;
+        for (int m = rg; m < M; m += 16) s += x[(size_t)m * ld + n];
+    red[rg][c] = s;
     __syncthreads();
-    if (w == 0 && n < N) {
-        const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (rg == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][c];
         out[n] = accumulate ? out[n] + t : t;
     }
 }
@@ -599,7 +603,7 @@ int mpo_launch_gemm_mixed(const GemmGroup& grp, hipStream_t stream) {
 
 int mpo_launch_colsum(const float* x, float* out, int M, int N, int ld, int accumulate, hipStream_t stream) {
     if (N <= 0) return 0;
-    colsum_kernel<<<(N + 63) / 64, 256, 0, stream>>>(x, out, M, N, ld, accumulate);
+    colsum_kernel<<<(N + 15) / 16, 256, 0, stream>>>(x, out, M, N, ld, accumulate);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -223,7 +223,9 @@ int mpo_launch_bias_relu_dropout_bf16(void* h, const float* bias, size_t rows, i
                                       unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
                                       hipStream_t stream);
 // g = dy * (h > 0 ? 1/(1-p) : 0) on bf16 tensors (derivative of the same epilogue)
-int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, size_t n, float drop_p, hipStream_t stream);
+int mpo_relu_dropout_bwd_blocks(size_t n, int with_colsum);
+int mpo_launch_relu_dropout_bwd_bf16(const void* h, const void* dy, void* g, size_t n, float drop_p, int cols,
+                                     float* part_colsum /* nullable [blocks][cols] */, hipStream_t stream);
 
 int mpo_launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                          float wd, int step, const int* step_dev, hipStream_t stream);
@@ -249,8 +251,8 @@ int mpo_launch_bag_colacc_gated(const void* bag, int bag_f32, const int* cu, int
                                 const float* w2map, float* part1, float* part2, int n_q, const BagPlan& plan,
                                 hipStream_t stream);
 int mpo_launch_bag_outer_gated(const float* kbag, const int* cu, int n_slides, int embed, const float* w1, const float* z1,
-                               const float* w2, const float* z2, void* dk, int dk_f32, int n_q, const BagPlan& plan,
-                               hipStream_t stream);
+                               const float* w2, const float* z2, void* dk, int dk_f32, float* part_colsum /* nullable */,
+                               int n_q, const BagPlan& plan, hipStream_t stream);
 
 // 'ces' survival loss (tail.hip)
 int mpo_launch_ces_loss_fwd(const float* hazards, const float* survs, const long long* label, const float* cens, float* loss,

@@ -302,17 +302,22 @@ class PatchFcFn(torch.autograd.Function):
         if ctx.pre_gated:
             g = dh
         else:
-            g = torch.empty_like(dh)
-            L.check(lib.mpo_patch_epilogue_backward(L.ptr(h), L.ptr(dh), L.ptr(g), g.numel(), ctx.drop_p,
-                                                    L.stream_of(g)), "mpo_patch_epilogue_backward")
+            g = None
         dw, db = (grad_out(p) for p in ctx.param_refs)
-        _splitk_tn(g, x, dw)
-        ready = getattr(dh, "_mpo_colsum", None) if ctx.pre_gated else None
-        if ready is not None and ready.shape == db.shape:
-            db.copy_(ready)                 # produced by the co-attention backward kernel while it wrote dh
-            stats["colsum_handoffs"] += 1
+        if g is None:                       # ReLU/dropout derivative + the bias gradient (column sums) in one pass
+            g = torch.empty_like(dh)
+            ws = _workspace(lib.mpo_patch_epilogue_backward_workspace_bytes(g.numel(), g.shape[1]), g.device)
+            L.check(lib.mpo_patch_epilogue_backward(L.ptr(h), L.ptr(dh), L.ptr(g), g.numel(), g.shape[1], ctx.drop_p,
+                                                    L.ptr(db), L.ptr(ws), ws.numel(), L.stream_of(g)),
+                    "mpo_patch_epilogue_backward")
         else:
-            _colsum_two_stage(g, db)
+            ready = getattr(dh, "_mpo_colsum", None)
+            if ready is not None and ready.shape == db.shape:
+                db.copy_(ready)             # produced by the co-attention backward kernel while it wrote dh
+                stats["colsum_handoffs"] += 1
+            else:
+                _colsum_two_stage(g, db)
+        _splitk_tn(g, x, dw)
         return None, dw, db, None, None
 
 
@@ -790,7 +795,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
             L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
             _epoch(), L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
-            L.ptr(d_query), L.ptr(d_k), L.bag_dtype_code(d_k), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
+            L.ptr(d_query), L.ptr(d_k), L.bag_dtype_code(d_k), L.ptr(d_in_b[E:2 * E]), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
             L.ptr(d_out_b), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
         # back through the caller-side GEMM  K = H W_k^T + b_k.  The forward K stays fp32 (the gate amplifies its
         # rounding); its GRADIENT goes through bf16 operands with fp32 accumulation for a bf16 bag: dW_k as a
@@ -800,11 +805,10 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         if bag_data.dtype == torch.bfloat16:
             d_h.addmm_(d_k, w_k.to(torch.bfloat16))       # in place: the out-of-place form first copies d_h (98 us for 245 MB)
             _splitk_tn(d_k, bag_data, d_in_w[E:2 * E])
-            _colsum_two_stage(d_k, d_in_b[E:2 * E])
         else:
             d_h.addmm_(d_k, w_k)
             torch.mm(d_k.t(), bag_data, out=d_in_w[E:2 * E])
-            d_in_b[E:2 * E] = d_k.sum(0)
+        # (d_in_b[E:2E], the key bias gradient = column sums of d_k, came out of the kernel that wrote d_k)
         return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None
 
 
