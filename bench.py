@@ -164,8 +164,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-    dev = torch.device("cuda", local)
+        # "nccl" is RCCL.  MPO_DIST_BACKEND=gloo exists to rehearse the N > 1 code path with several ranks sharing
+        # one card (RCCL refuses two ranks on the same device); the driver's runs never set it.
+        dist.init_process_group(os.environ.get("MPO_DIST_BACKEND", "nccl"))
+    dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     bag_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
