@@ -76,29 +76,38 @@ def make_windows(n_windows, window, patches, dev, bag_dtype, seed, ragged=False,
     return out
 
 
-def roofline_leg(dev, window, patches, bag_dtype, reps=20):
-    """Time the K1 forward bag-pass kernel alone (HIP events on the launching stream) over a window
-    of H_bag-like bags; algorithmic bytes = M*d*e per slide."""
+def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
+    """Time the model's cross-attention forward bag-pass kernel alone (HIP events on the launching stream) over a
+    window of bags; algorithmic bytes = M*d*e per slide.  MCAT: K1's coattn_fwd_partial over H_bag in
+    the bag dtype.  NaCAGaT: K2's bag_rowdot_gated over the key bag, which is fp32 whatever the bag dtype (e = 4)."""
     from multimodal_path_omic_amd import _lib as L
     from multimodal_path_omic_amd.ops import BagBatch, make_cu
     E, n_q = 256, 6
-    esz = 2 if bag_dtype == torch.bfloat16 else 4
+    k2 = kind == "nacagat"
+    store = torch.float32 if k2 else bag_dtype
+    esz = 4 if store == torch.float32 else 2
     lengths = [patches] * window
     cu = make_cu(lengths, dev)
-    bags = [torch.relu(torch.randn(window * patches, E, device=dev)).to(bag_dtype) for _ in range(2)]
+    bags = [torch.relu(torch.randn(window * patches, E, device=dev)).to(store) for _ in range(2)]
     batch = BagBatch(bags[0], cu, lengths)
     plan = batch.plan()
     qk2 = torch.randn(window * n_q, E, device=dev) * 0.05
+    tq = torch.tanh(torch.randn(window * n_q, E, device=dev))
     lib = L.lib()
     parts = lib.mpo_coattn_target_workgroups() + window
     part_ml = torch.empty(parts * 32, device=dev)
     part_ctx = torch.empty(parts * n_q * E, device=dev)
+    maps = torch.empty(2, n_q * window * patches, device=dev) if k2 else None
     stream = torch.cuda.current_stream(dev)
 
     def launch(i):
-        L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), L.bag_dtype_code(bags[0]), L.ptr(cu), window, E,
-                                           L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, patches, plan,
-                                           stream.cuda_stream), "mpo_coattn_fwd_bagpass")
+        if k2:
+            L.check(lib.mpo_nacagat_fwd_bagpass(L.ptr(bags[i & 1]), L.ptr(cu), window, E, L.ptr(qk2), L.ptr(tq), L.ptr(maps[0]),
+                                                L.ptr(maps[1]), n_q, patches, plan, stream.cuda_stream), "mpo_nacagat_fwd_bagpass")
+        else:
+            L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), L.bag_dtype_code(bags[0]), L.ptr(cu), window, E,
+                                               L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, patches, plan,
+                                               stream.cuda_stream), "mpo_coattn_fwd_bagpass")
     for i in range(3):
         launch(i)
     torch.cuda.synchronize(dev)
@@ -113,11 +122,12 @@ def roofline_leg(dev, window, patches, bag_dtype, reps=20):
     alg_bytes = window * patches * E * esz
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "k1_fwd_traffic.json")
-    if os.path.exists(tpath):
+    tpath = os.path.join(ROOT, "profiles", "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json")
+    if os.path.exists(tpath) and window == 32 and patches == 15000 and (k2 or esz == 2):   # the configuration it was collected on
         with open(tpath) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
-    return {"bound": "hbm", "kernel": "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32"),
+    name = "bag_rowdot_gated_kernel<256,f32 key bag>" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
+    return {"bound": "hbm", "kernel": name,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_us, 2),
@@ -242,7 +252,7 @@ def main():
                        "patches_per_slide": "uniform[2000,30000] (fixed multiset)" if a.ragged else a.patches,
                        "parallelism": f"dp{world}", "resident_windows": a.n_windows, "launch": graph_note},
         }
-        out["roofline"] = roofline_leg(dev, a.window, a.patches, bag_dtype)
+        out["roofline"] = roofline_leg(dev, a.window, a.patches, bag_dtype, a.model)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(a.model, a.patches)
         print(json.dumps(out), flush=True)

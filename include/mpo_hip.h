@@ -258,6 +258,10 @@ int mpo_coattn_splits(int n_slides, int max_rows);
 int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
                            const float* qk2, float* part_ml, float* part_ctx, float* raw_logits /* nullable */,
                            int n_q, int max_rows, const mpo_bag_plan* plan /* nullable */, mpo_stream_t stream);
+/* K2's forward bag pass on its own (both score maps from one pass over the fp32 key bag): a_map, g_map [n_q*total_rows] */
+int mpo_nacagat_fwd_bagpass(const float* kbag, const int32_t* cu_rows, int n_slides, int embed, const float* qs2,
+                            const float* tq, float* a_map, float* g_map, int n_q, int max_rows,
+                            const mpo_bag_plan* plan /* nullable */, mpo_stream_t stream);
 int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
                            const float* qk2, const float* lse2, const float* dctx, const float* delta,
                            const float* d_attn_map /* nullable */, void* d_bag, float* part_dqk,

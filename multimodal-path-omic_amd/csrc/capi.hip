@@ -438,6 +438,13 @@ int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_row
     return mpo_launch_coattn_fwd_partial(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, part_ml, part_ctx,
                                          raw_logits, n_q, plan, stream);
 }
+int mpo_nacagat_fwd_bagpass(const float* kbag, const int32_t* cu_rows, int n_slides, int embed, const float* qs2,
+                            const float* tq, float* a_map, float* g_map, int n_q, int max_rows, const mpo_bag_plan* plan_,
+                            mpo_stream_t stream) {
+    const BagPlan plan = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(plan, n_slides)) return rc;
+    return mpo_launch_bag_rowdot_gated(kbag, 1, cu_rows, n_slides, embed, qs2, tq, a_map, g_map, n_q, plan, stream);
+}
 int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
                            const float* qk2, const float* lse2, const float* dctx, const float* delta,
                            const float* d_attn_map, void* d_bag, float* part_dqk, int n_q, int max_rows,

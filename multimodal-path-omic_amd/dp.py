@@ -67,8 +67,11 @@ class FlatGradBucket:
         """Sum over ranks, divide by world size: with per-rank 1/grad_acc_step loss scaling the update
         equals the reference's accumulation over world_size * grad_acc_step slides."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+            if dist.get_backend(group) == "nccl":            # RCCL averages inside the collective: no extra 16 MB pass
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.div_(dist.get_world_size(group))
 
 
 class FlatAdam:
