@@ -134,6 +134,12 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
  * d_query, d_kbag (dk_dtype: a GRADIENT may be handed on in bf16), d_hbag (bag dtype) and the q / v / out-projection
  * gradients; the key slices of d_in_proj_* are zeroed (the caller back-propagates d_kbag through its GEMM).
  * d_kbag_colsum (nullable) receives the column sums of d_kbag (= the key bias gradient) from the pass that writes it. */
+/* K2's key projection for a bf16-stored bag: kbag[m][n] = sum_e hbag[m][e] w_k[n][e] + b_k[n] in fp32, with the fp32
+ * weights split into three bf16 terms inside the kernel (all 24 mantissa bits; the bag is exact in bf16) -- replaces the k slice of
+ * F.linear(key, in_proj_weight, in_proj_bias) at models/blocks.py:151-166 without an fp32 copy of the bag.
+ * w_k = in_proj_weight + embed*embed, b_k = in_proj_bias + embed (nullable). */
+int mpo_key_projection(const void* hbag_bf16, int64_t rows, int embed, const float* w_k, const float* b_k, float* kbag,
+                       mpo_stream_t stream);
 size_t mpo_nacagat_saved_floats(int n_slides, int n_q, int embed);
 size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_rows, int total_rows);
 int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,

@@ -438,6 +438,11 @@ int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_row
     return mpo_launch_coattn_fwd_partial(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, part_ml, part_ctx,
                                          raw_logits, n_q, plan, stream);
 }
+int mpo_key_projection(const void* hbag_bf16, int64_t rows, int embed, const float* w_k, const float* b_k, float* kbag,
+                       mpo_stream_t stream) {
+    MPO_CHECK(rows >= 1 && rows <= 0x7fffffff, "key projection: %lld rows out of range", (long long)rows);
+    return mpo_launch_key_proj(hbag_bf16, w_k, b_k, kbag, (int)rows, embed, stream);
+}
 int mpo_nacagat_fwd_bagpass(const float* kbag, const int32_t* cu_rows, int n_slides, int embed, const float* qs2,
                             const float* tq, float* a_map, float* g_map, int n_q, int max_rows, const mpo_bag_plan* plan_,
                             mpo_stream_t stream) {

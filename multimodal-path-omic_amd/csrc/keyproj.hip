@@ -1,0 +1,137 @@
+// Key projection of K2:  K[m][n] = sum_e H[m][e] * W_k[n][e] + b_k[n]   (models/blocks.py:151-166, the k = in-projection
+// of the key), for a bf16-stored bag H [rows][256] and fp32 W_k [256][256]; K leaves in fp32.
+//
+// NaCAGaT needs k explicitly and to ~fp32 accuracy (its gate multiplies k's rounding error).  H is EXACT in
+// bf16 (it is stored that way), so splitting only the weights, W = W_hi + W_mid + W_lo (three bf16 terms, 24 mantissa
+// bits: all of fp32), gives
+//     K = H W_hi^T + H W_mid^T + H W_lo^T      with fp32 accumulation, i.e. the fp32 GEMM's result
+// from three bf16 MFMAs per product -- no fp32 copy of the bag (0.12 ms) and no fp32 library GEMM (0.55 ms).  (Two terms
+// leave a 2^-17 weight residual, which NaCAGaT's gate amplified to 2.9e-3 on the peaky fixture's map.)
+//
+// Layout: a workgroup of 8 waves streams 32-row tiles of H; wave w owns output columns [32w, 32w+32) and keeps ITS slice
+// of the three weight terms in registers for the whole kernel (2 column tiles x 8 k-steps x 3 terms = 192 VGPRs; with
+// 16 waves x 16 columns the 128-register cap of a 1024-thread workgroup spilled), so W costs no
+// memory traffic at all after the prologue.  The H tile is staged once per workgroup into a double-buffered LDS image
+// (K1's swizzle: conflict-free ds_read_b128 row fragments) with the next tile's global loads in flight during the MFMAs.
+// HBM-bound: reads rows*512 B, writes rows*1024 B.
+#include "coattn_tile.h"
+#include "mpo_common.h"
+#include "mpo_kernels.h"
+
+namespace {
+
+constexpr int KP_E = 256;
+constexpr int KP_WAVES = 8;
+constexpr int KP_THREADS = KP_WAVES * 64;
+
+__global__ __launch_bounds__(KP_THREADS, 1)
+void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-byte chunks */, const float* __restrict__ w,
+                     const float* __restrict__ bias, float* __restrict__ kout, int rows) {
+    using G = TileGeom<KP_E>;
+    __shared__ __attribute__((aligned(16))) char img[2][G::TILEB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int n0 = 32 * wave;
+
+    // this wave's weight slice as MFMA B fragments: lane supplies W[n0 + 16 ct + c16][32 s + 8 g .. + 7], split in three
+    bf16x8 whi[2][G::KS], wmid[2][G::KS], wlo[2][G::KS];
+    float bcol[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const float* wr = w + (size_t)(n0 + 16 * ct + c16) * KP_E;
+        bcol[ct] = bias ? bias[n0 + 16 * ct + c16] : 0.f;
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(wr + 32 * s + 8 * g);
+            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(wr + 32 * s + 8 * g + 4);
+            const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 h = (__bf16)v[j];
+                const float r1 = v[j] - (float)h;
+                const __bf16 m = (__bf16)r1;
+                whi[ct][s][j] = h;
+                wmid[ct][s][j] = m;
+                wlo[ct][s][j] = (__bf16)(r1 - (float)m);
+            }
+        }
+    }
+
+    // cooperative staging: the tile is 32 rows x 32 chunks of 16 bytes; thread t moves chunks t and t + 512
+    const int ntiles = (rows + kTileRows - 1) / kTileRows;
+    static_assert(2 * KP_THREADS == kTileRows * 32, "two 16-byte chunks per thread per tile");
+    uint4 st[2];
+    auto fetch = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ci = tid + i * KP_THREADS;
+            const int r = ci >> 5, cc = ci & 31;
+            int row = tile * kTileRows + r;
+            row = row < rows ? row : rows - 1;                               // clamp: finite data, stores are guarded
+            st[i] = hbag[(size_t)row * 32 + cc];
+        }
+    };
+    int buf = 0;
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ci = tid + i * KP_THREADS;
+            const int r = ci >> 5, cc = ci & 31;
+            *reinterpret_cast<uint4*>(img[buf] + r * G::ROWB + ((cc ^ ((r & 7) << 1)) << 4)) = st[i];
+        }
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        // one barrier per tile: the other buffer was last read two barriers ago
+        __syncthreads();
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = f32x4{bcol[ct], bcol[ct], bcol[ct], bcol[ct]};
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            const bf16x8 a0 = row_frag<KP_E>(img[buf], 0, s, lane);
+            const bf16x8 a1 = row_frag<KP_E>(img[buf], 1, s, lane);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                acc[0][ct] = mfma_bf16(a0, whi[ct][s], acc[0][ct]);
+                acc[1][ct] = mfma_bf16(a1, whi[ct][s], acc[1][ct]);
+                acc[0][ct] = mfma_bf16(a0, wmid[ct][s], acc[0][ct]);
+                acc[1][ct] = mfma_bf16(a1, wmid[ct][s], acc[1][ct]);
+                acc[0][ct] = mfma_bf16(a0, wlo[ct][s], acc[0][ct]);
+                acc[1][ct] = mfma_bf16(a1, wlo[ct][s], acc[1][ct]);
+            }
+        }
+        // D[row = 4g + r][col = c16] of each 16 x 16 block
+        const int row0 = tile * kTileRows;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * pt + 4 * g + r;
+                if (row < rows) {
+                    float* o = kout + (size_t)row * KP_E + n0 + c16;
+                    o[0] = acc[pt][0][r];
+                    o[16] = acc[pt][1][r];
+                }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+}  // namespace
+
+int mpo_launch_key_proj(const void* hbag_bf16, const float* w, const float* bias, float* kout, int rows, int embed,
+                        hipStream_t stream) {
+    MPO_CHECK(embed == KP_E, "key projection kernel: embed_dim %d not built (256 only)", embed);
+    MPO_CHECK(rows >= 1, "key projection: no rows");
+    MPO_CHECK((reinterpret_cast<uintptr_t>(hbag_bf16) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0,
+              "key projection: bag and weight must be 16-byte aligned");
+    const int ntiles = (rows + kTileRows - 1) / kTileRows;
+    const int grid = ntiles < 256 ? ntiles : 256;                            // one persistent workgroup per CU
+    key_proj_kernel<<<grid, KP_THREADS, 0, stream>>>(static_cast<const uint4*>(hbag_bf16), w, bias, kout, rows);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}

@@ -260,3 +260,7 @@ int mpo_launch_ces_loss_fwd(const float* hazards, const float* survs, const long
 int mpo_launch_ces_loss_bwd(const float* hazards, const float* survs, const long long* label, const float* cens,
                             const float* d_loss, int d_loss_scalar, float* d_hazards, float* d_survs, int B, int C,
                             float alpha, float eps, hipStream_t s);
+
+// K2 key projection from a bf16 bag with hi/lo-split fp32 weights (keyproj.hip)
+int mpo_launch_key_proj(const void* hbag_bf16, const float* w, const float* bias, float* kout, int rows, int embed,
+                        hipStream_t stream);

@@ -757,7 +757,14 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         n_q = R // n_slides
         dev, T = query.device, batch.total_rows
         query = query.contiguous()
-        kbag = F.linear(bag_data.float(), in_w[E:2 * E], in_b[E:2 * E])
+        if bag_data.dtype == torch.bfloat16 and E == 256:
+            # HIP key projection: bf16 bag (exact) x fp32 weights split into three bf16 terms, fp32 accumulate and output
+            kbag = torch.empty(T, E, device=dev, dtype=torch.float32)
+            w_k, b_k = in_w[E:2 * E], in_b[E:2 * E]
+            L.check(lib.mpo_key_projection(L.ptr(bag_data), T, E, L.ptr(w_k), L.ptr(b_k), L.ptr(kbag), L.stream_of(query)),
+                    "mpo_key_projection")
+        else:
+            kbag = F.linear(bag_data.float(), in_w[E:2 * E], in_b[E:2 * E])
         q_proj = torch.empty(R, E, device=dev, dtype=torch.float32)
         out = torch.empty(R, E, device=dev, dtype=torch.float32)
         amap = torch.empty(n_q * T, device=dev, dtype=torch.float32)

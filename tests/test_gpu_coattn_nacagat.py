@@ -124,3 +124,24 @@ def test_nacagat_training_dropout_replays_through_oracle(dev):
     # a second call draws a different mask
     _, a2 = mod(query=qd, key=bd, value=bd)
     assert not torch.equal(a2 > 0, a > 0)
+
+
+@pytest.mark.parametrize("rows", [1, 33, 777, 15000, 70001])
+def test_key_projection_matches_fp32_linear(dev, rows):
+    """mpo_key_projection (bf16 bag x three-way-split fp32 weights, models/blocks.py:151-166 key slice) against the plain
+    fp32 linear on the same stored values: three bf16 terms carry all 24 mantissa bits of the weights, so the result is
+    the fp32 GEMM's up to summation order."""
+    from multimodal_path_omic_amd import _lib as L
+    g = torch.Generator().manual_seed(rows)
+    h = torch.relu(torch.randn(rows, C.E, generator=g)).to(torch.bfloat16)
+    w = torch.randn(C.E, C.E, generator=g) / 16
+    b = torch.randn(C.E, generator=g)
+    ref = torch.nn.functional.linear(h.double(), w.double(), b.double())
+    hd, wd, bd = h.to(dev), w.to(dev), b.to(dev)
+    out = torch.full((rows + 1, C.E), float("nan"), device=dev)                 # one guard row: nothing may be written past the end
+    L.check(L.lib().mpo_key_projection(L.ptr(hd), rows, C.E, L.ptr(wd), L.ptr(bd), L.ptr(out),
+                                       torch.cuda.current_stream().cuda_stream), "mpo_key_projection")
+    got = out[:rows].double().cpu()
+    assert torch.isnan(out[rows]).all()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
