@@ -14,6 +14,8 @@
 // memory traffic at all after the prologue.  The H tile is staged once per workgroup into a double-buffered LDS image
 // (K1's swizzle: conflict-free ds_read_b128 row fragments) with the next tile's global loads in flight during the MFMAs.
 // HBM-bound: reads rows*512 B, writes rows*1024 B.
+#include <type_traits>
+
 #include "coattn_tile.h"
 #include "mpo_common.h"
 #include "mpo_kernels.h"
@@ -29,6 +31,7 @@ void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-by
                      const float* __restrict__ bias, float* __restrict__ kout, int rows) {
     using G = TileGeom<KP_E>;
     __shared__ __attribute__((aligned(16))) char img[2][G::TILEB];
+    __shared__ __attribute__((aligned(16))) float sbias[KP_E];   // read at store time: LDS traffic does not touch vmcnt
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
@@ -36,11 +39,11 @@ void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-by
 
     // this wave's weight slice as MFMA B fragments: lane supplies W[n0 + 16 ct + c16][32 s + 8 g .. + 7], split in three
     bf16x8 whi[2][G::KS], wmid[2][G::KS], wlo[2][G::KS];
-    float bcol[2];
+    // (the weight fragment is the MFMA's A operand and the H rows its B operand: D[n = 4g + r][patch = c16], so a lane ends
+    //  up with FOUR CONSECUTIVE OUTPUT COLUMNS of one patch row -- one 16-byte store instead of four 4-byte ones)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const float* wr = w + (size_t)(n0 + 16 * ct + c16) * KP_E;
-        bcol[ct] = bias ? bias[n0 + 16 * ct + c16] : 0.f;
 #pragma unroll
         for (int s = 0; s < G::KS; ++s) {
             const f32x4 lo4 = *reinterpret_cast<const f32x4*>(wr + 32 * s + 8 * g);
@@ -58,11 +61,16 @@ void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-by
         }
     }
 
+    if (tid < KP_E) sbias[tid] = bias ? bias[tid] : 0.f;
+    __syncthreads();
+
     // cooperative staging: the tile is 32 rows x 32 chunks of 16 bytes; thread t moves chunks t and t + 512
     const int ntiles = (rows + kTileRows - 1) / kTileRows;
     static_assert(2 * KP_THREADS == kTileRows * 32, "two 16-byte chunks per thread per tile");
-    uint4 st[2];
-    auto fetch = [&](int tile) {
+    // TWO tiles are in flight in registers (sa: the next tile, sb: the one after): one tile of MFMA work (~0.7 us) does
+    // not cover an HBM round trip, and the 8 waves of the workgroup advance in lockstep behind one barrier per tile
+    uint4 sa[2], sb[2];
+    auto fetch = [&](uint4 (&st)[2], int tile) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ci = tid + i * KP_THREADS;
@@ -72,52 +80,83 @@ void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-by
             st[i] = hbag[(size_t)row * 32 + cc];
         }
     };
-    int buf = 0;
-    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    auto stage = [&](const uint4 (&st)[2], char* image) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ci = tid + i * KP_THREADS;
             const int r = ci >> 5, cc = ci & 31;
-            *reinterpret_cast<uint4*>(img[buf] + r * G::ROWB + ((cc ^ ((r & 7) << 1)) << 4)) = st[i];
+            *reinterpret_cast<uint4*>(image + r * G::ROWB + ((cc ^ ((r & 7) << 1)) << 4)) = st[i];
         }
-        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-        // one barrier per tile: the other buffer was last read two barriers ago
-        __syncthreads();
+    };
+    auto compute = [&](const char* image, int tile, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;       // FULL: all 32 rows exist -> unconditional stores
         f32x4 acc[2][2];
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = f32x4{bcol[ct], bcol[ct], bcol[ct], bcol[ct]};
+        for (int ct = 0; ct < 2; ++ct) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + n0 + 16 * ct + 4 * g);   // columns n0 + 16 ct + 4g .. + 3
+            acc[0][ct] = b4;
+            acc[1][ct] = b4;
+        }
 #pragma unroll
         for (int s = 0; s < G::KS; ++s) {
-            const bf16x8 a0 = row_frag<KP_E>(img[buf], 0, s, lane);
-            const bf16x8 a1 = row_frag<KP_E>(img[buf], 1, s, lane);
+            const bf16x8 a0 = row_frag<KP_E>(image, 0, s, lane);
+            const bf16x8 a1 = row_frag<KP_E>(image, 1, s, lane);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                acc[0][ct] = mfma_bf16(a0, whi[ct][s], acc[0][ct]);
-                acc[1][ct] = mfma_bf16(a1, whi[ct][s], acc[1][ct]);
-                acc[0][ct] = mfma_bf16(a0, wmid[ct][s], acc[0][ct]);
-                acc[1][ct] = mfma_bf16(a1, wmid[ct][s], acc[1][ct]);
-                acc[0][ct] = mfma_bf16(a0, wlo[ct][s], acc[0][ct]);
-                acc[1][ct] = mfma_bf16(a1, wlo[ct][s], acc[1][ct]);
+                acc[0][ct] = mfma_bf16(whi[ct][s], a0, acc[0][ct]);
+                acc[1][ct] = mfma_bf16(whi[ct][s], a1, acc[1][ct]);
+                acc[0][ct] = mfma_bf16(wmid[ct][s], a0, acc[0][ct]);
+                acc[1][ct] = mfma_bf16(wmid[ct][s], a1, acc[1][ct]);
+                acc[0][ct] = mfma_bf16(wlo[ct][s], a0, acc[0][ct]);
+                acc[1][ct] = mfma_bf16(wlo[ct][s], a1, acc[1][ct]);
             }
         }
-        // D[row = 4g + r][col = c16] of each 16 x 16 block
+        // D[n = 4g + r][patch = c16] of each 16 x 16 block: lane -> K[row0 + 16 pt + c16][n0 + 16 ct + 4g .. + 3]
         const int row0 = tile * kTileRows;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 16 * pt + 4 * g + r;
-                if (row < rows) {
-                    float* o = kout + (size_t)row * KP_E + n0 + c16;
-                    o[0] = acc[pt][0][r];
-                    o[16] = acc[pt][1][r];
-                }
+            const int row = row0 + 16 * pt + c16;
+            if (FULL || row < rows) {
+                float* o = kout + (size_t)row * KP_E + n0 + 4 * g;
+                *reinterpret_cast<f32x4*>(o) = acc[pt][0];
+                *reinterpret_cast<f32x4*>(o + 16) = acc[pt][1];
             }
         }
-        buf ^= 1;
+    };
+    // Control flow is kept uniform -- fetches are unconditional with the tile index clamped to the last tile (a few
+    // redundant loads at the tail) -- so that the compiler's waitcnt bookkeeping sees ONE steady-state pattern and waits
+    // with vmcnt(n > 0): conditional fetches made it fall back to vmcnt(0) before every LDS write, i.e. to waiting for
+    // the previous tile's stores and the other prefetch set as well, which serialised loads, MFMAs and stores.
+    const int stride = gridDim.x;
+    const int last = ntiles - 1;
+    auto clampt = [&](int t) { return t < last ? t : last; };
+    int tile = blockIdx.x;
+    fetch(sa, clampt(tile));
+    fetch(sb, clampt(tile + stride));
+    // two tiles per trip so that the register sets keep their roles; one barrier per tile (the buffer written now
+    // was last read two barriers ago)
+    const int full_tiles = rows / kTileRows;                   // tiles below this index have all 32 rows
+    using Full = std::integral_constant<bool, true>;
+    using Guarded = std::integral_constant<bool, false>;
+    // steady state: both tiles of the trip are full -> no predicated memory operation anywhere in the loop body
+    for (; tile + stride < full_tiles; tile += 2 * stride) {
+        stage(sa, img[0]);
+        fetch(sa, clampt(tile + 2 * stride));
+        __syncthreads();
+        compute(img[0], tile, Full());
+        stage(sb, img[1]);
+        fetch(sb, clampt(tile + 3 * stride));
+        __syncthreads();
+        compute(img[1], tile + stride, Full());
+    }
+    // tail: at most one trip per workgroup with guarded stores (the register sets already hold these tiles)
+    if (tile < ntiles) {
+        stage(sa, img[0]);
+        __syncthreads();
+        compute(img[0], tile, Guarded());
+        stage(sb, img[1]);
+        __syncthreads();
+        if (tile + stride < ntiles) compute(img[1], tile + stride, Guarded());
     }
 }
 
@@ -127,8 +166,9 @@ int mpo_launch_key_proj(const void* hbag_bf16, const float* w, const float* bias
                         hipStream_t stream) {
     MPO_CHECK(embed == KP_E, "key projection kernel: embed_dim %d not built (256 only)", embed);
     MPO_CHECK(rows >= 1, "key projection: no rows");
-    MPO_CHECK((reinterpret_cast<uintptr_t>(hbag_bf16) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0,
-              "key projection: bag and weight must be 16-byte aligned");
+    MPO_CHECK((reinterpret_cast<uintptr_t>(hbag_bf16) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(kout) & 15) == 0,
+              "key projection: bag, weight, bias and output must be 16-byte aligned");
     const int ntiles = (rows + kTileRows - 1) / kTileRows;
     const int grid = ntiles < 256 ? ntiles : 256;                            // one persistent workgroup per CU
     key_proj_kernel<<<grid, KP_THREADS, 0, stream>>>(static_cast<const uint4*>(hbag_bf16), w, bias, kout, rows);
