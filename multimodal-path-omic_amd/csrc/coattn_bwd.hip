@@ -29,7 +29,8 @@ struct BwdCfg {
     // the per-slide Z^T operand of the dH product lives in LDS (one copy per workgroup): as 64-128 registers per lane
     // it pushed the kernel far past the register file (1000+ accvgpr spill moves per pass over the loop)
     static constexpr int Z_BYTES = NT * TileGeom<E_>::DT * 64 * 16;
-    static constexpr int LDS_BYTES = TILES_BYTES + Z_BYTES;
+    static constexpr int DST_BYTES = F32BAG ? 0 : WAVES * 16 * kTileRows * 4;   // per-wave [16 queries][32 patches] pad
+    static constexpr int LDS_BYTES = TILES_BYTES + Z_BYTES + DST_BYTES;
 };
 
 // rows-on-lane orientation: out[pt][r] = sum_k x[4g + r][k] * tile[16pt + (lane&15)][k]
@@ -156,50 +157,94 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // ---------------- query on the lane: dS^T -> dqk accumulation
-        {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
-            tile_dot_rows<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
-            tile_dot_rows<E_, NT>(thi, tlo, dch, dcl, d0, d1, lane);
-            float ds[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
+        bf16x8 wph[2], wpl[2];
+        if constexpr (!F32BAG) {
+            // ---------------- patch on the lane: A, dS with the query index in the registers
+            // (The scores are computed in THIS orientation only.  The dqk accumulation below needs dS with the query on
+            //  the lane: it is transposed through a 2 KB LDS pad -- 8 scalar writes, 2 x 16-byte reads per lane -- instead of
+            //  recomputing both row products in the other orientation: 64 MFMAs and 32 tile reads less per tile.)
+            float* dsT = reinterpret_cast<float*>(lds + C::TILES_BYTES + C::Z_BYTES) + wave * (16 * kTileRows);   // [q][patch]
+            {
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+                tile_dot_rows_T<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
+                tile_dot_rows_T<E_, NT>(thi, tlo, dch, dcl, d0, d1, lane);
+    #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
-                    const int row = 16 * pt + 4 * g + r;
+                    const int row = 16 * pt + c16;
                     const bool ok = row < nvalid;
-                    float da = pt == 0 ? d0[r] : d1[r];
-                    if (da_b != nullptr && ok && c16 < n_q) da += da_b[(size_t)c16 * m_rows + trow + row];
-                    const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_q) : 0.f;
-                    ds[4 * pt + r] = a * (da - del_q);
+                    float w[8];
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qq = 4 * g + r;
+                        float da = pt == 0 ? d0[r] : d1[r];
+                        if (da_b != nullptr && ok && qq < n_q) da += da_b[(size_t)qq * m_rows + trow + row];
+                        const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_p[r]) : 0.f;
+                        w[r] = a;
+                        w[4 + r] = a * (da - del_p[r]);
+                        dsT[qq * kTileRows + row] = w[4 + r];
+                    }
+                    pack_hi_lo(w, wph[pt], wpl[pt]);
                 }
             }
-            bf16x8 wh, wl;
-            pack_hi_lo(ds, wh, wl);
-            tile_accum_cols<E_, NT>(thi, tlo, wh, wl, accq, lane);
-        }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 
-        // ---------------- patch on the lane: A, dS with the query index in the registers
-        bf16x8 wph[2], wpl[2];
-        {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
-            tile_dot_rows_T<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
-            tile_dot_rows_T<E_, NT>(thi, tlo, dch, dcl, d0, d1, lane);
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                const int row = 16 * pt + c16;
-                const bool ok = row < nvalid;
-                float w[8];
-#pragma unroll
+            // ---------------- query on the lane: dS^T -> dqk accumulation (reads the H image: before dH overwrites it)
+            {
+                // lane (q = c16, g) takes patches 4g..4g+3 and 16+4g..16+4g+3: the k-order of col_frag
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(dsT + c16 * kTileRows + 4 * g);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(dsT + c16 * kTileRows + 16 + 4 * g);
+                const float ds[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                bf16x8 wh, wl;
+                pack_hi_lo(ds, wh, wl);
+                tile_accum_cols<E_, NT>(thi, tlo, wh, wl, accq, lane);
+            }
+        } else {
+            // fp32 bag: both images + Z fill the 160 KB of LDS, no room for the pad -- both orientations are recomputed
+            // ---------------- query on the lane: dS^T -> dqk accumulation
+            {
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+                tile_dot_rows<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
+                tile_dot_rows<E_, NT>(thi, tlo, dch, dcl, d0, d1, lane);
+                float ds[8];
+    #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int qq = 4 * g + r;
-                    float da = pt == 0 ? d0[r] : d1[r];
-                    if (da_b != nullptr && ok && qq < n_q) da += da_b[(size_t)qq * m_rows + trow + row];
-                    const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_p[r]) : 0.f;
-                    w[r] = a;
-                    w[4 + r] = a * (da - del_p[r]);
+    #pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const int row = 16 * pt + 4 * g + r;
+                        const bool ok = row < nvalid;
+                        float da = pt == 0 ? d0[r] : d1[r];
+                        if (da_b != nullptr && ok && c16 < n_q) da += da_b[(size_t)c16 * m_rows + trow + row];
+                        const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_q) : 0.f;
+                        ds[4 * pt + r] = a * (da - del_q);
+                    }
                 }
-                pack_hi_lo(w, wph[pt], wpl[pt]);
+                bf16x8 wh, wl;
+                pack_hi_lo(ds, wh, wl);
+                tile_accum_cols<E_, NT>(thi, tlo, wh, wl, accq, lane);
+            }
+
+            // ---------------- patch on the lane: A, dS with the query index in the registers
+            {
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+                tile_dot_rows_T<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
+                tile_dot_rows_T<E_, NT>(thi, tlo, dch, dcl, d0, d1, lane);
+    #pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int row = 16 * pt + c16;
+                    const bool ok = row < nvalid;
+                    float w[8];
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qq = 4 * g + r;
+                        float da = pt == 0 ? d0[r] : d1[r];
+                        if (da_b != nullptr && ok && qq < n_q) da += da_b[(size_t)qq * m_rows + trow + row];
+                        const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_p[r]) : 0.f;
+                        w[r] = a;
+                        w[4 + r] = a * (da - del_p[r]);
+                    }
+                    pack_hi_lo(w, wph[pt], wpl[pt]);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
