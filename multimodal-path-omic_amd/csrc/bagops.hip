@@ -471,7 +471,7 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
         }
     };
     const int n_steps = 2 * sg.n_my;
-    static_assert(CH_PER_ROW == 64, "copy-out: a lane keeps one 4-column chunk (E = 256)");
+    static_assert(CH_PER_ROW <= 64 && 64 % CH_PER_ROW == 0, "copy-out: a lane keeps one 4-column chunk");
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};                       // column sums of the rows this lane copies out
     if (n_steps > 0) fetch(step_row(0));
     for (int st = 0; st < n_steps; ++st) {
@@ -546,7 +546,12 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
     }
     if (part_colsum != nullptr) {
         __syncthreads();
-        *reinterpret_cast<f32x4*>(img + lane * 16) = csum;               // lane == column chunk
+#pragma unroll
+        for (int o = CH_PER_ROW; o < 64; o <<= 1) {                      // lanes l, l + CH_PER_ROW, ... share a chunk
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csum[j] += __shfl_xor(csum[j], o);
+        }
+        if (lane < CH_PER_ROW) *reinterpret_cast<f32x4*>(img + lane * 16) = csum;   // lane == column chunk
         __syncthreads();
         for (int idx = threadIdx.x; idx < E_; idx += 256) {
             float a = 0.f;
@@ -1018,10 +1023,12 @@ int mpo_launch_bag_outer_gated(const float* kbag, const int* cu, int n_slides, i
                                const float* w2, const float* z2, void* dk, int dk_f32, float* part_colsum, int n_q,
                                const BagPlan& plan, hipStream_t stream) {
     (void)n_slides;
-    MPO_CHECK(embed == 256, "gated outer-product pass: embed_dim %d not built (256 only)", embed);
     dim3 grid = plan_grid(plan);
-    if (dk_f32) bag_outer_gated_kernel<256, false><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, part_colsum, n_q, plan);
-    else bag_outer_gated_kernel<256, true><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, part_colsum, n_q, plan);
+    if (dk_f32) {
+        MPO_E_SWITCH(embed, (bag_outer_gated_kernel<EV, false><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, part_colsum, n_q, plan)))
+    } else {
+        MPO_E_SWITCH(embed, (bag_outer_gated_kernel<EV, true><<<grid, 256, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, part_colsum, n_q, plan)))
+    }
     MPO_LAUNCH_CHECK();
     return 0;
 }

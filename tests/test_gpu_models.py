@@ -122,3 +122,34 @@ def test_window_equals_per_slide(dev, kind):
     for n, p in model.named_parameters():
         scale = max(float(p.grad.abs().max()), 1e-3)            # shift-invariant biases: ~1e-8 noise
         assert float((grads_w[n] - p.grad).abs().max()) / scale < 2e-4, n
+
+
+@pytest.mark.parametrize("kind", ["mcat", "nacagat"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_model_size_matches_oracle(dev, kind, dtype):
+    """model_size='small' (d = 128, models/mcat/mcat.py:16-17): the E = 128 instantiations of every bag kernel, forward
+    and gradients against the oracle (fed the same stored values for the bf16 bag)."""
+    omic_sizes, m, seed = [64, 100, 256, 31, 8, 300], 1500, 5150
+    cls = MultimodalCoAttentionTransformer if kind == "mcat" else NarrowContextualAttentionGateTransformer
+    model = cls(omic_sizes=omic_sizes, model_size="small", bag_dtype=dtype)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert shapes["H.0.weight"] == (128, 1024)
+    sd = syn.fill_state_dict(shapes, seed)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    wsi, omics, _, _ = C.model_inputs(m, omic_sizes, seed + 1)
+    hz, sv, y, att = model(wsi=wsi.to(dev), omics=[o.to(dev) for o in omics])
+    label, censor = torch.tensor([1]), torch.tensor([0.0])
+    ces_loss(hz, sv, label.to(dev), censor.to(dev)).backward()
+    fwd = O.mcat_forward if kind == "mcat" else O.nacagat_forward
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kw = dict(bag_storage=torch.bfloat16) if dtype == torch.bfloat16 else {}
+    hz_o, sv_o, _, _ = fwd(p, wsi, omics, **kw)
+    assert float((hz.cpu() - hz_o).abs().max()) < 2e-4
+    O.ces_loss(hz_o, sv_o, label, censor).backward()
+    for n, prm in model.named_parameters():
+        ref = p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])
+        scale = max(float(ref.abs().max()), 1e-4)
+        err = float((prm.grad.cpu() - ref).abs().max()) / scale
+        tol = 2e-3 if dtype == torch.float32 else (2e-2 if n.startswith("H.") else 1e-2)
+        assert err < tol, (n, err)
