@@ -232,7 +232,6 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                              float* d_in_b, float* d_out_w, float* d_out_b, float bag_relu_gate, const mpo_bag_plan* plan_,
                              void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
-    MPO_CHECK(embed != 512, "coattn backward: embed_dim 512 ('big') is not built yet");
     MPO_CHECK(!d_attn_map || attn_map, "coattn backward: a gradient on the attention map needs the forward's map");
     const int E = embed, R = n_slides * n_q;
     const BagPlan plan = make_plan(plan_, n_slides, max_rows);

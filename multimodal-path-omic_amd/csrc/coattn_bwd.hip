@@ -23,7 +23,7 @@ namespace {
 template <int E_, bool F32BAG>
 struct BwdCfg {
     static constexpr int NT = F32BAG ? 2 : 1;
-    static constexpr int WAVES = (F32BAG && E_ == 512) ? 2 : 4;
+    static constexpr int WAVES = E_ == 512 ? (F32BAG ? 1 : 2) : 4;
     static constexpr int WAVE_LDS = NT * TileGeom<E_>::TILEB;     // also holds the dH image (E*2*32 or E*4*32 bytes)
     static constexpr int TILES_BYTES = WAVES * WAVE_LDS;
     // the per-slide Z^T operand of the dH product lives in LDS (one copy per workgroup): as 64-128 registers per lane
@@ -135,9 +135,10 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
     // column sums of the emitted dH (= the bias gradient of the layer that produced the bag when the ReLU gate is on):
     // in the copy-out loop a lane always handles the same 16-byte column chunk, so it keeps that chunk's sums
     constexpr int CS_N = 16 / EB;                                 // elements per 16-byte chunk
-    float csum[CS_N];
+    constexpr int CS_CPL = (E_ * EB / 16 + 63) / 64;              // chunk columns a lane alternates between (2 at E=512 fp32)
+    float csum[CS_CPL * CS_N];
 #pragma unroll
-    for (int j = 0; j < CS_N; ++j) csum[j] = 0.f;
+    for (int j = 0; j < CS_CPL * CS_N; ++j) csum[j] = 0.f;
 
     Stage<E_, F32BAG> st0;
     Stage<E_, F32BAG> st1;
@@ -298,11 +299,11 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                     if (part_colsum != nullptr) {
                         if constexpr (F32BAG) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) csum[j] += v[j];
+                            for (int j = 0; j < 4; ++j) csum[(i % CS_CPL) * CS_N + j] += v[j];
                         } else {
                             const bf16x8 hv = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) csum[j] += (float)hv[j];
+                            for (int j = 0; j < 8; ++j) csum[(i % CS_CPL) * CS_N + j] += (float)hv[j];
                         }
                     }
                 }
@@ -330,16 +331,18 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
     if (part_colsum != nullptr) {                                 // same exchange for the column sums
         __syncthreads();
         constexpr int CH_PER_ROW = E_ * EB / 16;
-        static_assert(CH_PER_ROW <= 64 && 64 % CH_PER_ROW == 0, "a lane must keep one column chunk across the copy-out");
+        static_assert(CH_PER_ROW % 64 == 0 || 64 % CH_PER_ROW == 0, "a lane must keep fixed column chunks across the copy-out");
 #pragma unroll
         for (int o = CH_PER_ROW; o < 64; o <<= 1) {               // lanes l, l + CH_PER_ROW, ... share a chunk
 #pragma unroll
-            for (int j = 0; j < CS_N; ++j) csum[j] += __shfl_xor(csum[j], o);
+            for (int j = 0; j < CS_CPL * CS_N; ++j) csum[j] += __shfl_xor(csum[j], o);
         }
         float* wc = reinterpret_cast<float*>(thi);
         if (lane < CH_PER_ROW) {
 #pragma unroll
-            for (int j = 0; j < CS_N; ++j) wc[(lane % CH_PER_ROW) * CS_N + j] = csum[j];
+            for (int k = 0; k < CS_CPL; ++k)
+#pragma unroll
+                for (int j = 0; j < CS_N; ++j) wc[(lane % CH_PER_ROW + 64 * k) * CS_N + j] = csum[k * CS_N + j];
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < E_; idx += WAVES * 64) {
@@ -426,8 +429,9 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
     switch (embed) {
         MPO_BWD_CASE(128)
         MPO_BWD_CASE(256)
+        MPO_BWD_CASE(512)
         default:
-            mpo_set_error("coattn backward: embed_dim %d not in {128,256}", embed);
+            mpo_set_error("coattn backward: embed_dim %d not in {128,256,512}", embed);
             return 1;
     }
 #undef MPO_BWD_CASE
