@@ -61,6 +61,14 @@ class BagBatch:
         data = bags[0] if len(bags) == 1 else torch.cat(bags, 0)
         return BagBatch(data.contiguous(), make_cu(lengths, data.device), lengths)
 
+    @staticmethod
+    def from_lengths(data: torch.Tensor, lengths: "List[int]") -> "BagBatch":
+        """Rows already concatenated (e.g. a window slab shipped by ingest.WindowFeeder)."""
+        lengths = [int(m) for m in lengths]
+        if int(data.shape[0]) != sum(lengths):
+            raise ValueError(f"{int(data.shape[0])} rows for lengths summing to {sum(lengths)}")
+        return BagBatch(data, make_cu(lengths, data.device), lengths)
+
     def with_data(self, data: torch.Tensor) -> "BagBatch":
         assert data.shape[0] == self.total_rows
         return BagBatch(data, self.cu, self.lengths, self._plan)
