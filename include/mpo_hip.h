@@ -222,6 +222,14 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
                              const float* d_y, float* d_hcat, float* const* grads, int phase,
                              void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
+/* ---- survival head alone (for fusion layers other than `concat`, whose MLP K6 has built in): hazards = sigmoid(logits),
+ * survs = cumprod(1 - hazards), Y = softmax(logits)  (models/mcat/mcat.py:130-138).  Gradients nullable. */
+int mpo_survival_head_forward(const float* logits, int n_slides, int n_classes, float* hazards, float* survs, float* y,
+                              mpo_stream_t stream);
+int mpo_survival_head_backward(const float* hazards, const float* survs, const float* y, const float* d_hazards,
+                               const float* d_survs, const float* d_y, int n_slides, int n_classes, float* d_logits,
+                               mpo_stream_t stream);
+
 /* ---- 'ces' survival loss = CrossEntropySurvivalLoss.forward, models/loss.py:5-28, for n_slides slides at once
  * (the reference calls it per slide, models/mcat/main.py:52); per-slide losses, no reduction.  risk (nullable)
  * receives -sum_j survs_j (models/mcat/main.py:56).  Backward takes the per-slide upstream gradient d_loss

@@ -429,6 +429,21 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- survival head alone
+// hazards = sigmoid(logits), survs = cumprod(1 - hazards), Y = softmax(logits)   (models/mcat/mcat.py:130-138)
+int mpo_survival_head_forward(const float* logits, int n_slides, int n_classes, float* hazards, float* survs, float* y,
+                              mpo_stream_t stream) {
+    MPO_CHECK(logits && hazards && survs && y, "survival head forward: null argument");
+    return mpo_launch_head_fwd(logits, hazards, survs, y, n_slides, n_classes, static_cast<hipStream_t>(stream));
+}
+int mpo_survival_head_backward(const float* hazards, const float* survs, const float* y, const float* d_hazards,
+                               const float* d_survs, const float* d_y, int n_slides, int n_classes, float* d_logits,
+                               mpo_stream_t stream) {
+    MPO_CHECK(hazards && survs && y && d_logits, "survival head backward: null argument");
+    return mpo_launch_head_bwd(hazards, survs, y, d_hazards, d_survs, d_y, d_logits, n_slides, n_classes,
+                               static_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------------------------------- 'ces' loss
 int mpo_ces_loss_forward(const float* hazards, const float* survs, const int64_t* label, const float* censorship,
                          int n_slides, int n_classes, float alpha, float eps, float* loss, float* risk, mpo_stream_t stream) {

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .blocks import AttentionNetGated, CoAttention, PreGatingContextualAttention
-from .fusion import ConcatFusion
+from .fusion import BilinearFusion, ConcatFusion, GatedConcatFusion
 from . import ops
 from .ops import BagBatch
 from .transformer import make_set_transformer
@@ -54,8 +54,10 @@ class _FusionModelBase(nn.Module):
         self.fusion = fusion
         if fusion == "concat":
             self.fusion_layer = ConcatFusion(dims=[d1, d1], hidden_size=d1, output_size=d1).to(device=device)
-        elif fusion in ("bilinear", "gated_concat"):
-            raise NotImplementedError(f"fusion '{fusion}' is a later row of the scope table (SURVEY.md 8(f) f4)")
+        elif fusion == "bilinear":            # models/mcat/mcat.py:73-74
+            self.fusion_layer = BilinearFusion(dim1=d1, dim2=d1, output_size=d1)
+        elif fusion == "gated_concat":        # :75-77
+            self.fusion_layer = GatedConcatFusion(dims=[d1, d1], hidden_size=d1, output_size=d1).to(device=device)
         else:
             raise RuntimeError(f"Fusion mechanism {fusion} not implemented")
         self.classifier = nn.Linear(d1, n_classes)
@@ -107,8 +109,7 @@ class _FusionModelBase(nn.Module):
                                          [list(self.path_transformer.layers), list(self.omic_transformer.layers)], self.training)
             a, h = ops.gated_pool_stacked(tokens, [self.path_attention_head, self.omic_attention_head],
                                           [self.path_rho, self.omic_rho], self.training)
-            hcat = h.transpose(0, 1).reshape(h.shape[1], -1)                  # (B, [h_path | h_omic]): one copy each way
-            hazards, survs, y = ops.fusion_head_cat(hcat, self.fusion_layer, self.classifier)
+            hazards, survs, y = self._fuse_and_head(h[0], h[1], h)
             return hazards, survs, y, {"coattn": a_coattn, "path": a[0], "omic": a[1]}
         fork = self.fork_omic_branch and g_bag.is_cuda
         if fork:
@@ -126,8 +127,19 @@ class _FusionModelBase(nn.Module):
                 t.record_stream(main)
         else:
             a_omic, h_omic = self._omic_branch(g_bag)
-        hazards, survs, y = ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
+        hazards, survs, y = self._fuse_and_head(h_path, h_omic)
         return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
+
+    def _fuse_and_head(self, h_path, h_omic, stacked=None):
+        """Fusion + classifier + survival head (models/mcat/mcat.py:119-138).  `concat` is one K6 call; the other fusion
+        layers (row f4) run their own forward, then the classifier GEMM and the HIP head."""
+        if self.fusion == "concat":
+            if stacked is not None:
+                hcat = stacked.transpose(0, 1).reshape(stacked.shape[1], -1)   # (B, [h_path | h_omic]): one copy each way
+                return ops.fusion_head_cat(hcat, self.fusion_layer, self.classifier)
+            return ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
+        fused = self.fusion_layer(h_path, h_omic)
+        return ops.survival_head(ops.linear(fused, self.classifier.weight, self.classifier.bias))
 
     fork_omic_branch = not bool(os.environ.get("MPO_NO_FORK"))
     batch_branches = not bool(os.environ.get("MPO_NO_BRANCH_BATCH"))     # A/B switch: fall back to two chains (+ fork)

@@ -645,6 +645,36 @@ def omic_snn(omics, g_modules, training: bool):
     return OmicSnnFn.apply(p, len(omics), *[o.float() for o in omics], *params)
 
 
+class SurvivalHeadFn(torch.autograd.Function):
+    """logits (B, C) -> hazards, survs, Y (models/mcat/mcat.py:130-138) on the HIP head kernels."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        lib = L.lib()
+        logits = logits.contiguous()
+        b, c = logits.shape
+        hz, sv, y = (torch.empty_like(logits) for _ in range(3))
+        L.check(lib.mpo_survival_head_forward(L.ptr(logits), b, c, L.ptr(hz), L.ptr(sv), L.ptr(y), L.stream_of(logits)),
+                "mpo_survival_head_forward")
+        ctx.save_for_backward(hz, sv, y)
+        return hz, sv, y
+
+    @staticmethod
+    def backward(ctx, dhz, dsv, dy):
+        lib = L.lib()
+        hz, sv, y = ctx.saved_tensors
+        b, c = hz.shape
+        dhz, dsv, dy = (t.contiguous() if t is not None else None for t in (dhz, dsv, dy))
+        dl = torch.empty_like(hz)
+        L.check(lib.mpo_survival_head_backward(L.ptr(hz), L.ptr(sv), L.ptr(y), L.ptr(dhz), L.ptr(dsv), L.ptr(dy), b, c,
+                                               L.ptr(dl), L.stream_of(hz)), "mpo_survival_head_backward")
+        return dl
+
+
+def survival_head(logits):
+    return SurvivalHeadFn.apply(logits)
+
+
 class CesLossFn(torch.autograd.Function):
     """'ces' loss (models/loss.py:5-28) for a whole window in one launch each way: per-slide losses + risks.
     The torch formulation costs ~60 tiny launches per window (cat/gather/clamp/log and their backward)."""

@@ -191,6 +191,33 @@ def concat_fusion(h_path, h_omic, p, prefix="fusion_layer"):
     return torch.relu(_lin(x, p, prefix + ".fusion_layer.2"))
 
 
+def gated_concat_fusion(h_path, h_omic, p, prefix="fusion_layer"):
+    """GatedConcatFusion, models/fusion.py:22-41: x_i * sigmoid(Linear_i(x_i)), cat, the ConcatFusion MLP.  The
+    reference's gates live in an unregistered list (:25-27); here they are parameters `<prefix>.gates.<i>.0.*`."""
+    items = []
+    for i, x in enumerate((h_path, h_omic)):
+        items.append(x * torch.sigmoid(_lin(x, p, f"{prefix}.gates.{i}.0")))
+    x = torch.cat(items, dim=0)
+    x = torch.relu(_lin(x, p, prefix + ".fusion_layer.0"))
+    return torch.relu(_lin(x, p, prefix + ".fusion_layer.2"))
+
+
+def bilinear_fusion(x1, x2, p, prefix="fusion_layer"):
+    """BilinearFusion, models/fusion.py:44-113 with its defaults (gates, bilinear, skip connection), eval mode."""
+    def bil(a, b, name):                      # nn.Bilinear: z_k = a^T W_k b + bias_k
+        return torch.einsum("i,kij,j->k", a, p[f"{prefix}.{name}.weight"], b) + p[f"{prefix}.{name}.bias"]
+    h1 = torch.relu(_lin(x1, p, prefix + ".linear_h1.0"))
+    o1 = torch.relu(_lin(torch.sigmoid(bil(x1, x2, "linear_z1")) * h1, p, prefix + ".linear_o1.0"))       # :88-91
+    h2 = torch.relu(_lin(x2, p, prefix + ".linear_h2.0"))
+    o2 = torch.relu(_lin(torch.sigmoid(bil(x2, x1, "linear_z2")) * h2, p, prefix + ".linear_o2.0"))       # :95-98
+    o1 = torch.cat([o1, torch.ones(1)])                                                                   # :103-106
+    o2 = torch.cat([o2, torch.ones(1)])
+    out = torch.outer(o1, o2).flatten()                                                                   # :107
+    out = torch.relu(_lin(out, p, prefix + ".fc1.0"))                                                     # :111
+    out = torch.cat([out, o1, o2])                                                                        # :112-113
+    return torch.relu(_lin(out, p, prefix + ".fc2.0"))                                                    # :114
+
+
 def survival_head(h, p, prefix="classifier"):
     """models/mcat/mcat.py:126-138: logits (1,C) -> hazards, survs = cumprod(1-hazards), Y = softmax."""
     logits = _lin(h, p, prefix).unsqueeze(0)
@@ -200,22 +227,22 @@ def survival_head(h, p, prefix="classifier"):
 
 
 # --------------------------------------------------------------------------- H1
-def _tail(h_coattn, g_bag, a_coattn, p):
+def _tail(h_coattn, g_bag, a_coattn, p, fusion="concat"):
     path = set_transformer(h_coattn, p, "path_transformer")
     omic = set_transformer(g_bag, p, "omic_transformer")
     a_path, h_path = gated_mil_pool(path, p, "path_attention_head", "path_rho")
     a_omic, h_omic = gated_mil_pool(omic, p, "omic_attention_head", "omic_rho")
-    h = concat_fusion(h_path, h_omic, p)
+    h = {"concat": concat_fusion, "gated_concat": gated_concat_fusion, "bilinear": bilinear_fusion}[fusion](h_path, h_omic, p)
     hazards, survs, y = survival_head(h, p)
     return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
 
 
-def mcat_forward(p, wsi, omics, inference=False, bag_storage=None):
+def mcat_forward(p, wsi, omics, inference=False, bag_storage=None, fusion="concat"):
     """MultimodalCoAttentionTransformer.forward, models/mcat/mcat.py:84-142 (eval mode)."""
     h_bag = patch_fc(wsi, p, storage=bag_storage)
     g_bag = omic_fc(omics, p)
     h_co, a_co = mcat_coattention(g_bag, h_bag, p, need_weights=inference)
-    return _tail(h_co, g_bag, a_co, p)
+    return _tail(h_co, g_bag, a_co, p, fusion)
 
 
 def nacagat_forward(p, wsi, omics, bag_storage=None):

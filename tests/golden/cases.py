@@ -72,6 +72,22 @@ FUSION_SHAPES = {
     "classifier.weight": (4, E), "classifier.bias": (4,)}
 
 
+# row f4 fusion layers (models/fusion.py:22-113) with the constructor arguments of models/mcat/mcat.py:73-77
+BILINEAR_SHAPES = {
+    "linear_h1.0.weight": (32, E), "linear_h1.0.bias": (32,),
+    "linear_z1.weight": (32, E, E), "linear_z1.bias": (32,),
+    "linear_o1.0.weight": (32, 32), "linear_o1.0.bias": (32,),
+    "linear_h2.0.weight": (32, E), "linear_h2.0.bias": (32,),
+    "linear_z2.weight": (32, E, E), "linear_z2.bias": (32,),
+    "linear_o2.0.weight": (32, 32), "linear_o2.0.bias": (32,),
+    "fc1.0.weight": (64, 33 * 33), "fc1.0.bias": (64,),
+    "fc2.0.weight": (E, 64 + 64 + 2), "fc2.0.bias": (E,)}
+GATED_CONCAT_SHAPES = {
+    "gates.0.0.weight": (1, E), "gates.0.0.bias": (1,), "gates.1.0.weight": (1, E), "gates.1.0.bias": (1,),
+    "fusion_layer.0.weight": (E, 2 * E), "fusion_layer.0.bias": (E,),
+    "fusion_layer.2.weight": (E, E), "fusion_layer.2.bias": (E,)}
+
+
 def model_shapes(omic_sizes, nacagat: bool, d=E):
     """Full state_dict listing in the reference's registration order
     (models/mcat/mcat.py:24-82, models/nacagat/nacagat.py:20-78)."""

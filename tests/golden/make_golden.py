@@ -200,6 +200,42 @@ def gen_fusion():
     save("fusion", out)
 
 
+def gen_fusion_next():
+    """Row f4: the reference's BilinearFusion and GatedConcatFusion (eval mode) on the vectors of fusion_inputs.
+    GatedConcatFusion keeps its gates in an unregistered list (models/fusion.py:25-27): their weights are pushed in
+    directly; the fixture names them gates.<i>.0.* like the build's registered ModuleList."""
+    from models.fusion import BilinearFusion, GatedConcatFusion
+    hp, ho, _ = C.fusion_inputs()
+    out = {}
+    # bilinear, constructed as models/mcat/mcat.py:73-74
+    fus = BilinearFusion(dim1=C.E, dim2=C.E, output_size=C.E).eval()
+    assert {k: tuple(v.shape) for k, v in fus.state_dict().items()} == C.BILINEAR_SHAPES
+    sd = syn.fill_state_dict(C.BILINEAR_SHAPES, 710, gain=3.0)
+    fus.load_state_dict(sd, strict=True)
+    a, b = hp.clone().requires_grad_(True), ho.clone().requires_grad_(True)
+    y = fus(a, b)
+    probe = syn.normal(syn.rng(711), tuple(y.shape))
+    named = [("h_path", a), ("h_omic", b)] + list(fus.named_parameters())
+    out["bilinear/out"] = y
+    for n, g in grads_of((y * probe).sum(), named).items():
+        out["bilinear/grad/" + n] = sub(g)
+    # gated concat, constructed as models/mcat/mcat.py:75-77
+    fus = GatedConcatFusion(dims=[C.E, C.E], hidden_size=C.E, output_size=C.E).eval()
+    sd = syn.fill_state_dict(C.GATED_CONCAT_SHAPES, 720)
+    fus.load_state_dict({k: v for k, v in sd.items() if not k.startswith("gates.")}, strict=True)
+    for i, gate in enumerate(fus.gates):
+        gate[0].weight.data.copy_(sd[f"gates.{i}.0.weight"])
+        gate[0].bias.data.copy_(sd[f"gates.{i}.0.bias"])
+    a, b = hp.clone().requires_grad_(True), ho.clone().requires_grad_(True)
+    y = fus(a, b)
+    named = ([("h_path", a), ("h_omic", b)] + list(fus.named_parameters())
+             + [(f"gates.{i}.0.{n}", p) for i, gate in enumerate(fus.gates) for n, p in gate[0].named_parameters()])
+    out["gated_concat/out"] = y
+    for n, g in grads_of((y * probe).sum(), named).items():
+        out["gated_concat/grad/" + n] = sub(g)
+    save("fusion_next", out)
+
+
 # ----------------------------------------------------------------------------- H1
 def build_model(kind, omic_sizes, seed):
     cls = MultimodalCoAttentionTransformer if kind == "mcat" else NarrowContextualAttentionGateTransformer
@@ -296,6 +332,6 @@ def gen_cohort():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["coattn_mcat", "coattn_nacagat", "cag", "encoder", "pool", "fusion",
-                             "models", "loss", "cohort"]
+                             "models", "loss", "cohort", "fusion_next"]
     for w in which:
         globals()["gen_" + w]()

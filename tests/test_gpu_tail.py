@@ -234,3 +234,71 @@ def test_ces_loss_kernel_matches_reference_kat_golden_and_oracle_gradients(dev, 
         ((per_d * weights.to(dev)).sum() if weights is not None else per_d.sum() / 8).backward()
         torch.testing.assert_close(hz_d.grad.cpu(), hz_o.grad, rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(sv_d.grad.cpu(), sv_o.grad, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("kind", ["bilinear", "gated_concat"])
+def test_fusion_next_rows_match_golden(dev, golden, kind):
+    """Row f4 on the GPU: BilinearFusion / GatedConcatFusion (HIP GEMMs + element-wise device ops) against the
+    reference's golden outputs and gradients, per slide (the reference's 1-D call) and for a window of slides."""
+    from multimodal_path_omic_amd.fusion import BilinearFusion, GatedConcatFusion
+    g = golden("fusion_next")
+    if kind == "bilinear":
+        fus = BilinearFusion(dim1=C.E, dim2=C.E, output_size=C.E)
+        sd = syn.fill_state_dict(C.BILINEAR_SHAPES, 710, 3.0)
+    else:
+        fus = GatedConcatFusion(dims=[C.E, C.E], hidden_size=C.E, output_size=C.E)
+        sd = syn.fill_state_dict(C.GATED_CONCAT_SHAPES, 720)
+    assert {k: tuple(v.shape) for k, v in fus.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    fus.load_state_dict(sd, strict=True)
+    fus.to(dev).eval()
+    hp, ho, _ = C.fusion_inputs()
+    hpd, hod = hp.to(dev).requires_grad_(True), ho.to(dev).requires_grad_(True)
+    y = fus(hpd, hod)
+    assert y.shape == g[f"{kind}/out"].shape
+    assert relerr(y, g[f"{kind}/out"]) < 1e-4
+    probe = syn.normal(syn.rng(711), tuple(y.shape)).to(dev)
+    names = ["h_path", "h_omic"] + list(sd)
+    params = dict(fus.named_parameters())
+    gs = torch.autograd.grad((y * probe).sum(), [hpd, hod] + [params[k] for k in sd])
+    check_grads(g, f"{kind}/grad/", names, gs)
+    # window form: rows are independent slides
+    hw = torch.stack([hp, ho * 0.5, -hp]).to(dev), torch.stack([ho, hp, ho * 2.0]).to(dev)
+    yw = fus(*hw)
+    for b in range(3):
+        assert relerr(yw[b], fus(hw[0][b], hw[1][b])) < 1e-5
+
+
+def test_gated_concat_loads_a_reference_checkpoint_without_gate_entries(dev):
+    """The reference never registers its gates (models/fusion.py:25-27), so its checkpoints have no gates.* keys."""
+    from multimodal_path_omic_amd.fusion import GatedConcatFusion
+    fus = GatedConcatFusion(dims=[C.E, C.E], hidden_size=C.E, output_size=C.E)
+    before = {k: v.clone() for k, v in fus.gates.state_dict().items()}
+    ref_like = {k: v for k, v in syn.fill_state_dict(C.GATED_CONCAT_SHAPES, 720).items() if not k.startswith("gates.")}
+    fus.load_state_dict(ref_like, strict=True)
+    for k, v in fus.gates.state_dict().items():
+        assert torch.equal(v, before[k])
+
+
+@pytest.mark.parametrize("fusion", ["bilinear", "gated_concat"])
+def test_model_with_other_fusion_matches_oracle(dev, fusion):
+    """Whole MCAT with `fusion=` bilinear / gated_concat (models/mcat/mcat.py:69-79): hazards and gradients vs the oracle."""
+    from multimodal_path_omic_amd.harness import ces_loss
+    from multimodal_path_omic_amd.models import MultimodalCoAttentionTransformer
+    from oracle import mpo_oracle as O
+    omic_sizes, m, seed = [64, 100, 256, 31, 8, 300], 900, 7170
+    model = MultimodalCoAttentionTransformer(omic_sizes=omic_sizes, fusion=fusion)
+    sd = syn.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    wsi, omics, _, _ = C.model_inputs(m, omic_sizes, seed + 1)
+    hz, sv, y, _ = model(wsi=wsi.to(dev), omics=[o.to(dev) for o in omics])
+    label, censor = torch.tensor([2]), torch.tensor([0.0])
+    ces_loss(hz, sv, label.to(dev), censor.to(dev)).backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hz_o, sv_o, _, _ = O.mcat_forward(p, wsi, omics, fusion=fusion)
+    assert float((hz.cpu() - hz_o).abs().max()) < 1e-4
+    O.ces_loss(hz_o, sv_o, label, censor).backward()
+    for n, prm in model.named_parameters():
+        ref = p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])
+        scale = max(float(ref.abs().max()), 1e-4)
+        assert float((prm.grad.cpu() - ref).abs().max()) / scale < (1e-2 if n.startswith("H.") else 2e-3), n

@@ -185,3 +185,21 @@ def test_c_index_hand_cases():
     assert ci([1, 0, 1, 1], [1., 2., 3., 4.], [4., 3., 1., 2.]) == pytest.approx(0.75)
     with pytest.raises(ValueError):
         ci([0, 0], [1., 2.], [1., 2.])
+
+
+@pytest.mark.parametrize("kind", ["bilinear", "gated_concat"])
+def test_fusion_next_rows(golden, kind):
+    """Row f4: the oracle's BilinearFusion / GatedConcatFusion restatements against the reference's outputs and gradients."""
+    g = golden("fusion_next")
+    shapes, seed, gain = (C.BILINEAR_SHAPES, 710, 3.0) if kind == "bilinear" else (C.GATED_CONCAT_SHAPES, 720, 1.0)
+    p = leafify({"fusion_layer." + k: v for k, v in syn.fill_state_dict(shapes, seed, gain).items()})
+    hp, ho, _ = C.fusion_inputs()
+    hp.requires_grad_(True)
+    ho.requires_grad_(True)
+    y = (O.bilinear_fusion if kind == "bilinear" else O.gated_concat_fusion)(hp, ho, p)
+    close(y, g[f"{kind}/out"])
+    probe = syn.normal(syn.rng(711), tuple(y.shape))
+    named = [("h_path", hp), ("h_omic", ho)] + [(k[len("fusion_layer."):], v) for k, v in p.items()]
+    for n, gr in grads((y * probe).sum(), named).items():
+        ref = g[f"{kind}/grad/{n}"]
+        close(sub(gr), ref, rtol=1e-3, atol=2e-5 * max(1.0, float(ref.abs().max())))
