@@ -204,10 +204,12 @@ def main():
         try:
             graphed, pool = [], None
             for w in windows:
-                gs = GraphedWindowStep(model, bucket, w, a.window, opt=opt if world == 1 else None, pool=pool)
+                gs = GraphedWindowStep(model, bucket, w, a.window, opt=opt if world == 1 else None, pool=pool,
+                                       split_patch_grad=world > 1)
                 pool = gs.pool()
                 graphed.append(gs)
-            graph_note = "hipgraph(fwd+bwd+adam)" if world == 1 else "hipgraph(fwd+bwd)+eager allreduce/adam"
+            graph_note = ("hipgraph(fwd+bwd+adam)" if world == 1 else
+                          "hipgraph(fwd+bwd) | allreduce(rest) overlapped with hipgraph(dW_H) | allreduce(dW_H) | adam")
         except Exception as e:                                    # same kernels either way; say so in the output
             graphed, graph_note = None, f"eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})"
             torch.cuda.synchronize(dev)
@@ -215,9 +217,18 @@ def main():
     def step(i):
         if graphed is None:
             return eager_step(i)
-        graphed[i % len(graphed)]()
+        gs = graphed[i % len(graphed)]
+        gs()
         if world > 1:
-            bucket.all_reduce_mean()
+            # the one exchange step of the path, split so that most of it hides behind the patch layer's weight-gradient
+            # GEMM: everything but that gradient is ready after the main graph
+            head = gs.head_numel()
+            rest = bucket.all_reduce_mean_async(lo=head)
+            gs.replay_tail()
+            first = bucket.all_reduce_mean_async(lo=0, hi=head)
+            for h in (rest, first):
+                if h is not None:
+                    h.wait()
             opt.step()
 
     for i in range(a.warmup):

@@ -74,6 +74,24 @@ class FlatGradBucket:
                 self.flat.div_(dist.get_world_size(group))
 
 
+    def all_reduce_mean_async(self, lo: int = 0, hi: int = None, group=None):
+        """Start the mean all-reduce of flat[lo:hi] and return a handle whose wait() orders the current stream behind it
+        (None when there is nothing to reduce): lets the caller keep computing into OTHER slices of the bucket meanwhile."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return None
+        view = self.flat[lo:hi]
+        if dist.get_backend(group) == "nccl":
+            return dist.all_reduce(view, op=dist.ReduceOp.AVG, group=group, async_op=True)
+        work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        world = dist.get_world_size(group)
+
+        class _Then:
+            def wait(self_inner):
+                work.wait()
+                view.div_(world)
+        return _Then()
+
+
 class FlatAdam:
     """torch.optim.Adam(lr, betas, eps, weight_decay) (the reference's default optimiser,
     models/mcat/main.py:284-300) as ONE HIP kernel over flat buffers: parameters are re-pointed at slices of

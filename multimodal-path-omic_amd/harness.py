@@ -100,10 +100,19 @@ class GraphedWindowStep:
     out (`opt=None`): replay, then all-reduce the bucket and step eagerly.
     """
 
-    def __init__(self, model, bucket, window, grad_acc_step: int, opt=None, warmup: int = 2, pool=None):
+    def __init__(self, model, bucket, window, grad_acc_step: int, opt=None, warmup: int = 2, pool=None,
+                 split_patch_grad: bool = False):
+        """split_patch_grad (data-parallel steps, opt=None): the patch layer's weight gradient -- a 0.3 ms GEMM nobody
+        downstream waits for -- is captured into a SECOND graph, `replay_tail()`.  The caller replays the main graph,
+        starts the all-reduce of every other gradient (bucket.all_reduce_mean_async(lo=head)), replays the tail while
+        that collective runs, then reduces the head slice: the exchange step hides behind compute."""
         from . import ops
         self.model, self.bucket, self.opt = model, bucket, opt
         self.window, self.acc = window, grad_acc_step
+        self.split = bool(split_patch_grad)
+        if self.split and opt is not None:
+            raise ValueError("split_patch_grad is for steps whose optimiser runs after an all-reduce (opt=None)")
+        self.tail_graph = None
         window[0].plan()                      # the work plan's H2D copy must not happen inside the capture
         dev = bucket.flat.device
         if ops._rng_epoch_tensor is None:
@@ -118,17 +127,39 @@ class GraphedWindowStep:
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other threads (RCCL's watchdog under torch.distributed) may issue HIP calls meanwhile
         with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
-            self.loss, self.risk = self._body()
+            self.loss, self.risk = self._body(flush=not self.split)
+        if self.split:
+            self._held = list(ops._deferred_patch)          # keep the queued operands alive between the two graphs
+            self.tail_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.tail_graph, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                ops.flush_patch_weight_grads()
 
-    def _body(self):
+    def _body(self, flush: bool = True):
+        from . import ops
         self.epoch += 1
         self.bucket.begin()
         bags, omics, labels, cens = self.window
-        out = train_window(self.model, bags, omics, labels, cens, self.acc)
+        ops.defer_patch_weight_grad = self.split
+        try:
+            out = train_window(self.model, bags, omics, labels, cens, self.acc)
+        finally:
+            ops.defer_patch_weight_grad = False
         self.bucket.finish()
+        if self.split and flush:
+            ops.flush_patch_weight_grads()
         if self.opt is not None:
             self.opt.step()
         return out
+
+    def head_numel(self) -> int:
+        """Number of leading bucket elements that only replay_tail() writes (the patch layer's weight)."""
+        p = self.model.H[0].weight
+        assert p._mpo_grad_view.data_ptr() == self.bucket.flat.data_ptr(), "H.0.weight must lead the gradient bucket"
+        return p.numel()
+
+    def replay_tail(self):
+        if self.tail_graph is not None:
+            self.tail_graph.replay()
 
     def pool(self):
         return self.graph.pool()

@@ -279,6 +279,19 @@ def coattn_mcat(query, batch: BagBatch, in_w, in_b, out_w, out_b, need_weights: 
 
 stats = {"colsum_handoffs": 0}           # counters the tests read to make sure a fused path really ran
 
+# Data-parallel steps split the backward in two: everything except the patch layer's weight gradient (dW_H = g^T X, a
+# 0.3 ms library GEMM that nothing downstream waits for) runs first, then the all-reduce of all other gradients is
+# started and dW_H is computed WHILE that collective runs (harness.GraphedWindowStep(split_patch_grad=True)).
+defer_patch_weight_grad = False
+_deferred_patch = []
+
+
+def flush_patch_weight_grads():
+    """Compute the patch-layer weight gradients PatchFcFn.backward queued (into the bucket slices it already returned)."""
+    for g, x, dw in _deferred_patch:
+        _splitk_tn(g, x, dw)
+    _deferred_patch.clear()
+
 
 # ------------------------------------------------------------------------------------ patch layer (row H2)
 class PatchFcFn(torch.autograd.Function):
@@ -325,7 +338,11 @@ class PatchFcFn(torch.autograd.Function):
                 stats["colsum_handoffs"] += 1
             else:
                 _colsum_two_stage(g, db)
-        _splitk_tn(g, x, dw)
+        if defer_patch_weight_grad and getattr(ctx.param_refs[0], "_mpo_grad_view", None) is not None \
+                and dw.data_ptr() == ctx.param_refs[0]._mpo_grad_view.data_ptr():
+            _deferred_patch.append((g, x, dw))      # dw aliases the bucket slice: filled by flush_patch_weight_grads()
+        else:
+            _splitk_tn(g, x, dw)
         return None, dw, db, None, None
 
 

@@ -45,7 +45,12 @@ def _worker(rank, world, port, out):
     for i in mine:
         (_loss(model, slides[i]) / len(mine)).backward()          # per-rank 1/grad_acc_step scaling
     bucket.finish()
-    bucket.all_reduce_mean()
+    # the split exchange of the window step (dp.FlatGradBucket.all_reduce_mean_async): tail slice first, head slice second,
+    # must equal one all_reduce_mean over the whole bucket
+    head = bucket.flat.numel() // 3
+    handles = [bucket.all_reduce_mean_async(lo=head), bucket.all_reduce_mean_async(lo=0, hi=head)]
+    for h in handles:
+        h.wait()
     opt.step()
     if rank == 0:
         torch.save([p.detach().clone() for p in model.parameters()], out)
