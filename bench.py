@@ -121,15 +121,19 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
     avg_us = sum(us) / len(us)
     alg_bytes = window * patches * E * esz
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    traffic = None
+    traffic, mfma_util = None, None
     tpath = os.path.join(ROOT, "profiles", "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json")
     if os.path.exists(tpath) and window == 32 and patches == 15000 and (k2 or esz == 2):   # the configuration it was collected on
         with open(tpath) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            prof = json.load(f)
+        traffic = prof.get("hbm_bytes_per_launch")
+        busy = prof.get("mfma", {}).get("SQ_VALU_MFMA_BUSY_CYCLES")
+        if busy:                      # PMC busy cycles (summed over SIMDs) against this run's measured launch time
+            mfma_util = round(busy / (4 * 256 * avg_us * 1e-6 * 2.4e9), 4)
     name = "bag_rowdot_gated_kernel<256,f32 key bag>" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
     return {"bound": "hbm", "kernel": name,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_util": mfma_util,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_us, 2),
             "min_launch_us": round(us[0], 2), "launches_timed": reps}
 
