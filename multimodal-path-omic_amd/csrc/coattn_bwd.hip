@@ -29,7 +29,9 @@ struct BwdCfg {
     // the per-slide Z^T operand of the dH product lives in LDS (one copy per workgroup): as 64-128 registers per lane
     // it pushed the kernel far past the register file (1000+ accvgpr spill moves per pass over the loop)
     static constexpr int Z_BYTES = NT * TileGeom<E_>::DT * 64 * 16;
-    static constexpr int DST_BYTES = F32BAG ? 0 : WAVES * 16 * kTileRows * 4;   // per-wave [16 queries][32 patches] pad
+    static constexpr int DST_LD = kTileRows + 4;                  // row stride of the pad in floats: 36 keeps the four
+                                                                  // lane groups of a write on different banks (32 = 4-way)
+    static constexpr int DST_BYTES = F32BAG ? 0 : WAVES * 16 * DST_LD * 4;      // per-wave [16 queries][32 patches] pad
     static constexpr int LDS_BYTES = TILES_BYTES + Z_BYTES + DST_BYTES;
 };
 
@@ -164,7 +166,7 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
             // (The scores are computed in THIS orientation only.  The dqk accumulation below needs dS with the query on
             //  the lane: it is transposed through a 2 KB LDS pad -- 8 scalar writes, 2 x 16-byte reads per lane -- instead of
             //  recomputing both row products in the other orientation: 64 MFMAs and 32 tile reads less per tile.)
-            float* dsT = reinterpret_cast<float*>(lds + C::TILES_BYTES + C::Z_BYTES) + wave * (16 * kTileRows);   // [q][patch]
+            float* dsT = reinterpret_cast<float*>(lds + C::TILES_BYTES + C::Z_BYTES) + wave * (16 * C::DST_LD);   // [q][patch]
             {
                 f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
                 tile_dot_rows_T<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
@@ -182,7 +184,7 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                         const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_p[r]) : 0.f;
                         w[r] = a;
                         w[4 + r] = a * (da - del_p[r]);
-                        dsT[qq * kTileRows + row] = w[4 + r];
+                        dsT[qq * C::DST_LD + row] = w[4 + r];
                     }
                     pack_hi_lo(w, wph[pt], wpl[pt]);
                 }
@@ -193,8 +195,8 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
             // ---------------- query on the lane: dS^T -> dqk accumulation (reads the H image: before dH overwrites it)
             {
                 // lane (q = c16, g) takes patches 4g..4g+3 and 16+4g..16+4g+3: the k-order of col_frag
-                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(dsT + c16 * kTileRows + 4 * g);
-                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(dsT + c16 * kTileRows + 16 + 4 * g);
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(dsT + c16 * C::DST_LD + 4 * g);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(dsT + c16 * C::DST_LD + 16 + 4 * g);
                 const float ds[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
                 bf16x8 wh, wl;
                 pack_hi_lo(ds, wh, wl);
