@@ -134,6 +134,14 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
  * d_query, d_kbag (dk_dtype: a GRADIENT may be handed on in bf16), d_hbag (bag dtype) and the q / v / out-projection
  * gradients; the key slices of d_in_proj_* are zeroed (the caller back-propagates d_kbag through its GEMM).
  * d_kbag_colsum (nullable) receives the column sums of d_kbag (= the key bias gradient) from the pass that writes it. */
+/* ---- ragged attention maps (slide b's [n_q][M_b] block at float offset n_q * cu_rows[b]), for the attention-regularised
+ * loss CrossEntropySurvivalAttnRegLoss (models/loss.py:88-101: + lambda * ||A||_2 per slide):
+ * out[b][q] = sum_m a[q][m] * b[q][m];   out_map block b = scale[b] * a block b. */
+int mpo_map_block_dot(const float* a_map, const float* b_map, const int32_t* cu_rows, int n_slides, int n_q, float* out,
+                      mpo_stream_t stream);
+int mpo_map_block_scale(const float* a_map, const float* scale, const int32_t* cu_rows, int n_slides, int n_q, float* out,
+                        mpo_stream_t stream);
+
 /* K2's key projection for a bf16-stored bag: kbag[m][n] = sum_e hbag[m][e] w_k[n][e] + b_k[n] in fp32, with the fp32
  * weights split into three bf16 terms inside the kernel (all 24 mantissa bits; the bag is exact in bf16) -- replaces the k slice of
  * F.linear(key, in_proj_weight, in_proj_bias) at models/blocks.py:151-166 without an fp32 copy of the bag.

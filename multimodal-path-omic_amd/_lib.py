@@ -34,6 +34,8 @@ _SIGNATURES = {
     "mpo_linear_backward_weight": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "mpo_coattn_splits": (c_int, [c_int, c_int]),
     "mpo_coattn_target_workgroups": (c_int, []),
+    "mpo_map_block_dot": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "mpo_map_block_scale": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "mpo_key_projection": (c_int, [_P, ctypes.c_int64, c_int, _P, _P, _P, _P]),
     "mpo_nacagat_fwd_bagpass": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "mpo_coattn_fwd_bagpass": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P]),

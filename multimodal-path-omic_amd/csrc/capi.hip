@@ -437,6 +437,17 @@ int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_row
     return mpo_launch_coattn_fwd_partial(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, part_ml, part_ctx,
                                          raw_logits, n_q, plan, stream);
 }
+// per-(query, slide) dot products over the ragged maps, and the per-slide scaling that is the backward of a map norm
+int mpo_map_block_dot(const float* a_map, const float* b_map, const int32_t* cu_rows, int n_slides, int n_q, float* out,
+                      mpo_stream_t stream) {
+    MPO_CHECK(a_map && b_map && cu_rows && out && n_slides >= 1 && n_q >= 1, "map block dot: bad argument");
+    return mpo_launch_map_rowdot(a_map, b_map, cu_rows, out, n_slides, n_q, 0, stream);
+}
+int mpo_map_block_scale(const float* a_map, const float* scale, const int32_t* cu_rows, int n_slides, int n_q, float* out,
+                        mpo_stream_t stream) {
+    MPO_CHECK(a_map && scale && cu_rows && out && n_slides >= 1 && n_q >= 1, "map block scale: bad argument");
+    return mpo_launch_map_block_scale(a_map, scale, cu_rows, out, n_slides, n_q, stream);
+}
 int mpo_key_projection(const void* hbag_bf16, int64_t rows, int embed, const float* w_k, const float* b_k, float* kbag,
                        mpo_stream_t stream) {
     MPO_CHECK(rows >= 1 && rows <= 0x7fffffff, "key projection: %lld rows out of range", (long long)rows);

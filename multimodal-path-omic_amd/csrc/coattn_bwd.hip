@@ -408,7 +408,25 @@ __global__ void map_rowdot_kernel(const float* __restrict__ a_map, const float* 
     }
 }
 
+// out[q-row of slide b][m] = scale[b] * a[..][m]  over a slide's ragged [n_q][M_b] block (backward of a per-slide map norm)
+__global__ void map_block_scale_kernel(const float* __restrict__ a_map, const float* __restrict__ scale, const int* __restrict__ cu,
+                                       float* __restrict__ out, int n_q) {
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int row_begin = cu[b], m_rows = cu[b + 1] - row_begin;
+    const size_t base = (size_t)n_q * row_begin + (size_t)q * m_rows;
+    const float sc = scale[b];
+    for (int m = threadIdx.x; m < m_rows; m += blockDim.x) out[base + m] = sc * a_map[base + m];
+}
+
 }  // namespace
+
+int mpo_launch_map_block_scale(const float* a_map, const float* scale, const int* cu, float* out, int n_slides, int n_q,
+                               hipStream_t stream) {
+    dim3 grid(n_q, n_slides);
+    map_block_scale_kernel<<<grid, 256, 0, stream>>>(a_map, scale, cu, out, n_q);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
 
 int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                           const float* qk2, const float* lse2, const float* dctx, const float* delta,

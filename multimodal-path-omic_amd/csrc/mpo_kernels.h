@@ -153,6 +153,8 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
 int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, const BagPlan& plan,
                                  hipStream_t stream);
 int mpo_launch_rowdot(const float* a, const float* b, float* out, int rows, int cols, hipStream_t stream);
+int mpo_launch_map_block_scale(const float* a_map, const float* scale, const int* cu, float* out, int n_slides, int n_q,
+                               hipStream_t stream);
 int mpo_launch_map_rowdot(const float* a_map, const float* da_map, const int* cu, float* delta, int n_slides, int n_q,
                           int accumulate, hipStream_t stream);
 

@@ -65,13 +65,21 @@ def make_window(slides: Sequence[dict], device, bag_dtype=torch.float32):
     return bags, omics, labels, cens
 
 
-def train_window(model, bags: BagBatch, omics, labels, cens, grad_acc_step: int):
+def train_window(model, bags: BagBatch, omics, labels, cens, grad_acc_step: int, loss: str = "ces", lambda_reg: float = 0.01):
     """Forward + backward of one window; gradients ACCUMULATE into .grad with the reference's
     1/grad_acc_step scaling per slide (models/mcat/main.py:69-70).  Returns (per-slide loss, risk) tensors
-    on the device -- no host sync."""
-    hazards, survs, _, _ = model.forward_window(bags, omics)
+    on the device -- no host sync.  loss: 'ces' (models/loss.py:5-28) or 'cesar' (:88-101: ces + lambda_reg * ||A_b||_2 of
+    the slide's co-attention map, models/nacagat/main.py:49-50)."""
     from . import ops
-    per_slide, risk = ops.ces_loss(hazards, survs, labels, cens)              # one HIP launch each way
+    if loss == "cesar":
+        hazards, survs, _, att = model.forward_window(bags, omics, inference=True)    # the map is an output here
+        per_slide, risk = ops.ces_loss(hazards, survs, labels, cens)
+        per_slide = per_slide + lambda_reg * ops.map_block_norm(att["coattn"])
+    elif loss == "ces":
+        hazards, survs, _, _ = model.forward_window(bags, omics)
+        per_slide, risk = ops.ces_loss(hazards, survs, labels, cens)              # one HIP launch each way
+    else:
+        raise ValueError(f"loss '{loss}' is not built (ces | cesar)")
     # d(sum(loss) / grad_acc_step) / d(loss_b) = 1 / grad_acc_step: hand it over as a cached constant instead of
     # building the sum / div graph (five tiny launches per window)
     per_slide.backward(_slide_weights(per_slide.numel(), grad_acc_step, per_slide.device))

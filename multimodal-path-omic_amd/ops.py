@@ -74,12 +74,21 @@ class BagBatch:
         return BagBatch(data, self.cu, self.lengths, self._plan)
 
     def split_map(self, flat_map: torch.Tensor, n_q: int) -> "List[torch.Tensor]":
-        """Ragged attention map -> list of (n_q, M_b) views (slide b starts at n_q * cu[b])."""
-        out, off = [], 0
+        """Ragged attention map -> list of (n_q, M_b) views (slide b starts at n_q * cu[b]).  The list also carries the
+        flat tensor (`.flat`, `.batch`, `.n_q`) for window-level consumers such as the attention-regularised loss."""
+        out, off = RaggedMaps(), 0
+        out.flat, out.batch, out.n_q = flat_map, self, n_q
         for m in self.lengths:
             out.append(flat_map[n_q * off:n_q * (off + m)].view(n_q, m))
             off += m
         return out
+
+
+class RaggedMaps(list):
+    """list of per-slide (n_q, M_b) views + the flat ragged tensor they alias."""
+    flat: Optional[torch.Tensor] = None
+    batch: Optional["BagBatch"] = None
+    n_q: int = 0
 
 
 def make_cu(lengths, device):
@@ -660,6 +669,37 @@ def omic_snn(omics, g_modules, training: bool):
         params += [g[0][0].weight, g[0][0].bias, g[1][0].weight, g[1][0].bias]
     p = g_modules[0][0][2].p if training else 0.0
     return OmicSnnFn.apply(p, len(omics), *[o.float() for o in omics], *params)
+
+
+class MapBlockNormFn(torch.autograd.Function):
+    """Frobenius norm of every slide's (n_q, M_b) block of a ragged attention map -> (n_slides,)."""
+
+    @staticmethod
+    def forward(ctx, flat_map, batch: BagBatch, n_q: int):
+        lib = L.lib()
+        flat_map = flat_map.contiguous()
+        sq = torch.empty(batch.n_slides * n_q, device=flat_map.device, dtype=torch.float32)
+        L.check(lib.mpo_map_block_dot(L.ptr(flat_map), L.ptr(flat_map), L.ptr(batch.cu), batch.n_slides, n_q, L.ptr(sq),
+                                      L.stream_of(flat_map)), "mpo_map_block_dot")
+        norm = sq.view(batch.n_slides, n_q).sum(1).sqrt()
+        ctx.save_for_backward(flat_map, norm)
+        ctx.batch, ctx.n_q = batch, n_q
+        return norm
+
+    @staticmethod
+    def backward(ctx, d_norm):
+        lib = L.lib()
+        flat_map, norm = ctx.saved_tensors
+        scale = (d_norm / norm.clamp_min(1e-30)).contiguous()
+        d_map = torch.empty_like(flat_map)
+        L.check(lib.mpo_map_block_scale(L.ptr(flat_map), L.ptr(scale), L.ptr(ctx.batch.cu), ctx.batch.n_slides, ctx.n_q,
+                                        L.ptr(d_map), L.stream_of(flat_map)), "mpo_map_block_scale")
+        return d_map, None, None
+
+
+def map_block_norm(maps) -> torch.Tensor:
+    """maps: the RaggedMaps a window forward returns -> per-slide ||A_b||_2, differentiable into the flat map."""
+    return MapBlockNormFn.apply(maps.flat, maps.batch, maps.n_q)
 
 
 class SurvivalHeadFn(torch.autograd.Function):

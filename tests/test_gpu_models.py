@@ -187,3 +187,37 @@ def test_big_mcat_matches_oracle(dev, dtype):
         # ARRIVING at H_bag agrees to 4e-6)
         tol = (1e-2 if n.startswith("H.") else 2e-3) if dtype == torch.float32 else (2e-2 if n.startswith("H.") else 1e-2)
         assert err < tol, (n, err)
+
+
+@pytest.mark.parametrize("kind", ["mcat", "nacagat"])
+def test_cesar_window_loss_matches_oracle(dev, kind):
+    """harness.train_window(loss='cesar'): ces + lambda ||A_b||_2 per slide (models/loss.py:88-101) over a ragged window,
+    with the norm's gradient entering the co-attention kernels through the flat map; against the oracle slide by slide."""
+    from multimodal_path_omic_amd import harness
+    from multimodal_path_omic_amd.dp import FlatGradBucket
+    omic_sizes, seed, lam = [64, 100, 256, 31, 8, 300], 888, 0.05
+    lengths = [300, 33, 1500, 77]
+    model, sd = build(kind, omic_sizes, seed, dev)
+    g = syn.rng(seed)
+    wsis = [syn.normal(g, (m, 1024)) for m in lengths]
+    omics = [[syn.normal(g, (s,)) for s in omic_sizes] for _ in lengths]
+    labels, cens = torch.tensor([0, 1, 2, 3]), torch.tensor([0., 1., 0., 1.])
+    bags = BagBatch.from_list([w.to(dev) for w in wsis])
+    om_w = [torch.stack([omics[b][i] for b in range(len(lengths))]).to(dev) for i in range(len(omic_sizes))]
+    bucket = FlatGradBucket(list(model.parameters()))
+    bucket.begin()
+    per_slide, risk = harness.train_window(model, bags, om_w, labels.to(dev), cens.to(dev), 4, loss="cesar", lambda_reg=lam)
+    bucket.finish()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fwd = O.mcat_forward if kind == "mcat" else O.nacagat_forward
+    for b in range(len(lengths)):
+        kw = dict(inference=True) if kind == "mcat" else {}
+        hz, sv, _, att = fwd(p, wsis[b], omics[b], **kw)
+        loss_b, _ = O.cesar_loss(hz, sv, labels[b:b + 1], cens[b:b + 1], att["coattn"], lambda_reg=lam)
+        assert per_slide[b].item() == pytest.approx(loss_b.item(), rel=2e-4, abs=2e-5)
+        (loss_b / 4).backward()
+    for n, prm in model.named_parameters():
+        ref = p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])
+        scale = max(float(ref.abs().max()), 1e-4)
+        err = float((prm.grad.cpu() - ref).abs().max()) / scale
+        assert err < (1e-2 if n.startswith("H.") else 3e-3), (n, err)
