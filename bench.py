@@ -181,6 +181,9 @@ def main():
         # "nccl" is RCCL.  MPO_DIST_BACKEND=gloo exists to rehearse the N > 1 code path with several ranks sharing
         # one card (RCCL refuses two ranks on the same device); the driver's runs never set it.
         dist.init_process_group(os.environ.get("MPO_DIST_BACKEND", "nccl"))
+    if a.gpus != world and rank == 0:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {a.gpus} "
+              f"(running with {world} rank(s))", file=sys.stderr)
     dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     bag_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
