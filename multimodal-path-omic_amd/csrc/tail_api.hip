@@ -3,6 +3,7 @@
 // Each entry is a fixed sequence of launches (GEMMs with fused epilogues/gates + the kernels of tail.hip)
 // on the caller's stream, in caller-provided buffers.
 #include <type_traits>
+#include <vector>
 
 #include "../../include/mpo_hip.h"
 #include "mpo_common.h"
@@ -124,6 +125,15 @@ namespace {
 // dropout stream of branch br inside one stream slot: branches are rows_x_width elements apart
 inline DropSpec drop_br(DropSpec d, int br, size_t elems_per_branch) { d.off += (uint64_t)br * ((elems_per_branch + 3) / 4); return d; }
 inline GateSpec gate_rng_br(DropSpec d, int br, size_t elems_per_branch) { return gate_rng(drop_br(d, br, elems_per_branch)); }
+// any number of same-layout products, eight members to a launch
+inline int launch_in_groups(const std::vector<GemmArgs>& list, int a_kc, int b_kc, hipStream_t stream) {
+    for (size_t i0 = 0; i0 < list.size(); i0 += 8) {
+        GemmGroup grp;
+        for (size_t i = i0; i < list.size() && i < i0 + 8; ++i) grp.g[grp.n++] = list[i];
+        if (int rc = mpo_launch_gemm_group(grp, a_kc, b_kc, stream)) return rc;
+    }
+    return 0;
+}
 struct GroupBuilder {
     GemmGroup g;
     int add(const GemmArgs& a) {
@@ -548,27 +558,26 @@ uint64_t mpo_omic_snn_rng_span(int n_slides, int n_groups, int d) { return 2ull 
 int mpo_omic_snn_forward(const float* const* x, const int* widths, int n_groups, int n_slides, int d,
                          const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
                          const uint64_t* rng_epoch, float* g_bag, float* saved, mpo_stream_t stream) {
-    MPO_CHECK(n_groups >= 1 && n_groups <= 8, "omic SNN: 1..8 groups per call (got %d)", n_groups);
+    MPO_CHECK(n_groups >= 1, "omic SNN: at least one group (got %d)", n_groups);
     const uint64_t stride = (uint64_t)n_slides * n_groups * d / 4 + 2;
     Carver c(saved);
-    GemmGroup l1, l2;
-    l1.n = l2.n = n_groups;
+    std::vector<GemmArgs> l1(n_groups), l2(n_groups);
     for (int i = 0; i < n_groups; ++i) {
         float* u1 = c.take((size_t)n_slides * d);
         const float* const* P = params + 4 * i;
-        GemmArgs& a = l1.g[i];
+        GemmArgs& a = l1[i];
         a.A = x[i]; a.B = P[0]; a.bias = P[1]; a.C = u1;
         a.M = n_slides; a.N = d; a.K = widths[i]; a.lda = widths[i]; a.ldb = widths[i]; a.ldc = d;
         a.act = MPO_ACT_ELU; a.alpha_dropout = 1; a.drop_p = drop_p; a.drop_seed = seed; a.drop_off = offset + stride * (2 * i);
         a.rng_epoch = reinterpret_cast<const unsigned long long*>(rng_epoch);
-        GemmArgs& b = l2.g[i];
+        GemmArgs& b = l2[i];
         b.A = u1; b.B = P[2]; b.bias = P[3]; b.C = g_bag + (size_t)i * d;
         b.M = n_slides; b.N = d; b.K = d; b.lda = d; b.ldb = d; b.ldc = n_groups * d;
         b.act = MPO_ACT_ELU; b.alpha_dropout = 1; b.drop_p = drop_p; b.drop_seed = seed; b.drop_off = offset + stride * (2 * i + 1);
         b.rng_epoch = a.rng_epoch;
     }
-    RC(mpo_launch_gemm_group(l1, 1, 1, stream));
-    RC(mpo_launch_gemm_group(l2, 1, 1, stream));
+    RC(launch_in_groups(l1, 1, 1, stream));
+    RC(launch_in_groups(l2, 1, 1, stream));
     return 0;
 }
 
@@ -576,12 +585,11 @@ int mpo_omic_snn_backward(const float* const* x, const int* widths, int n_groups
                           const float* const* params, float drop_p, uint64_t seed, uint64_t offset,
                           const uint64_t* rng_epoch, const float* g_bag, const float* saved, const float* d_g_bag,
                           float* const* grads, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
-    MPO_CHECK(n_groups >= 1 && n_groups <= 8, "omic SNN: 1..8 groups per call (got %d)", n_groups);
+    MPO_CHECK(n_groups >= 1, "omic SNN: at least one group (got %d)", n_groups);
     const uint64_t stride = (uint64_t)n_slides * n_groups * d / 4 + 2;
     Carver c(const_cast<float*>(saved));
     Arena ws(workspace, workspace_bytes);
-    GemmGroup dx, dw2, dw1;
-    dx.n = dw2.n = dw1.n = n_groups;
+    std::vector<GemmArgs> dx(n_groups), dw2(n_groups), dw1(n_groups);
     const unsigned long long* ep = reinterpret_cast<const unsigned long long*>(rng_epoch);
     for (int i = 0; i < n_groups; ++i) {
         const float* u1 = c.take((size_t)n_slides * d);
@@ -593,22 +601,22 @@ int mpo_omic_snn_backward(const float* const* x, const int* widths, int n_groups
         const float* y = g_bag + (size_t)i * d;
         const int ldy = n_groups * d;
         // layer 2: y = AD(ELU(u1 W2^T + b2)); gate indexed like y (row stride ldy) -> same stream index as forward
-        GemmArgs& a = dx.g[i];                               // du1 = (dy*gate) W2
+        GemmArgs& a = dx[i];                                 // du1 = (dy*gate) W2
         a.A = dy; a.B = P[2]; a.C = du1; a.M = n_slides; a.N = d; a.K = d; a.lda = ldy; a.ldb = d; a.ldc = d;
         a.gate = y; a.gate_mode = MPO_GATE_ELU_ADROP; a.gate_p = drop_p; a.gate_seed = seed; a.gate_off = offset + stride * (2 * i + 1);
         a.rng_epoch = ep;
-        GemmArgs& b = dw2.g[i];                              // dW2 = (dy*gate)^T u1, db2
+        GemmArgs& b = dw2[i];                                // dW2 = (dy*gate)^T u1, db2
         b.A = dy; b.B = u1; b.C = G[2]; b.bias_grad = G[3]; b.M = d; b.N = d; b.K = n_slides; b.lda = ldy; b.ldb = d; b.ldc = d;
         b.gate = y; b.gate_mode = MPO_GATE_ELU_ADROP; b.gate_p = drop_p; b.gate_seed = seed; b.gate_off = a.gate_off; b.rng_epoch = ep;
-        GemmArgs& e = dw1.g[i];                              // dW1 = (du1*gate1)^T x, db1   (x needs no gradient: it is data)
+        GemmArgs& e = dw1[i];                                // dW1 = (du1*gate1)^T x, db1   (x needs no gradient: it is data)
         e.A = du1; e.B = x[i]; e.C = G[0]; e.bias_grad = G[1]; e.M = d; e.N = widths[i]; e.K = n_slides; e.lda = d; e.ldb = widths[i];
         e.ldc = widths[i];
         e.gate = u1; e.gate_mode = MPO_GATE_ELU_ADROP; e.gate_p = drop_p; e.gate_seed = seed; e.gate_off = offset + stride * (2 * i);
         e.rng_epoch = ep;
     }
-    RC(mpo_launch_gemm_group(dx, 1, 0, stream));
-    RC(mpo_launch_gemm_group(dw2, 0, 0, stream));
-    RC(mpo_launch_gemm_group(dw1, 0, 0, stream));
+    RC(launch_in_groups(dx, 1, 0, stream));
+    RC(launch_in_groups(dw2, 0, 0, stream));
+    RC(launch_in_groups(dw1, 0, 0, stream));
     return 0;
 }
 

@@ -662,8 +662,6 @@ class OmicSnnFn(torch.autograd.Function):
 
 def omic_snn(omics, g_modules, training: bool):
     """omics: per group (B, d_i) -> G_bag (B, N, d).  g_modules: the nn.ModuleList self.G (parameter holders)."""
-    if len(omics) > 8:
-        raise NotImplementedError("omic SNN kernel: at most 8 omic groups per call")
     params = []
     for g in g_modules:
         params += [g[0][0].weight, g[0][0].bias, g[1][0].weight, g[1][0].bias]
