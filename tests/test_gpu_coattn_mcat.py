@@ -156,3 +156,40 @@ def test_coattn_rejects_bad_arguments(dev):
         mod(query=q.cpu(), key=bag.cpu(), value=bag.cpu())          # no CPU fallback
     with pytest.raises(RuntimeError):
         mod(query=torch.zeros(17, C.E, device=dev), key=bag, value=bag)   # > 16 queries
+
+
+@pytest.mark.parametrize("kind", ["mcat", "nacagat"])
+def test_full_slide_100k_patches_fp32(dev, kind):
+    """BASELINE cfg 5: one 100 000-patch fp32 bag (102.4 MB) through the co-attention of either model -- the split-M
+    partials over ~260 workgroups, the ragged map at full length and the gradients, against the oracle on the CPU."""
+    from multimodal_path_omic_amd.blocks import PreGatingContextualAttention
+    from oracle import mpo_oracle as O
+    m, seed = 100_000, 4321
+    q, bag, p_out, p_a = C.coattn_inputs(m, seed)
+    if kind == "mcat":
+        mod, p = make_module(seed, 1.0, dev)
+    else:
+        sd = syn.fill_state_dict(C.NACAGAT_COATTN_SHAPES, seed)
+        mod = PreGatingContextualAttention(embed_dim=C.E, num_heads=1)
+        mod.load_state_dict({k[len("co_attention."):]: v for k, v in sd.items()}, strict=True)
+        mod.to(dev).eval()
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    qo, bo = q.clone().requires_grad_(True), bag.clone().requires_grad_(True)
+    if kind == "mcat":
+        out_o, a_o = O.mcat_coattention(qo, bo, p, need_weights=True)
+    else:
+        out_o, a_o = O.pregating_contextual_attention(qo, bo, p)
+    named = [("query", qo), ("bag", bo)] + list(p.items())
+    # the map probe is scaled up: 100 000 entries of ~1e-5 each would otherwise not register against the output term
+    g_o = oracle_grads((out_o * p_out).sum() + 1e3 * (a_o * p_a).sum(), named)
+    qd, bd = q.to(dev).requires_grad_(True), bag.to(dev).requires_grad_(True)
+    out, a = mod(query=qd, key=bd, value=bd, need_weights=True) if kind == "mcat" else mod(query=qd, key=bd, value=bd)
+    assert a.shape == (C.N_OMIC, m)
+    assert relerr(out, out_o) < 2e-4
+    assert ((a.detach().cpu() - a_o.detach()).abs() / a_o.detach().clamp_min(1e-30)).max().item() < 1e-3
+    torch.testing.assert_close(a.sum(1).cpu(), torch.ones(C.N_OMIC), rtol=1e-4, atol=1e-4)
+    params = dict(mod.named_parameters())
+    tensors = [qd, bd] + [params[k[len("co_attention."):]] for k in p]
+    gs = torch.autograd.grad((out * p_out.to(dev)).sum() + 1e3 * (a * p_a.to(dev)).sum(), tensors)
+    for (n, _), gr in zip(named, gs):
+        assert relerr(gr, g_o[n]) < 3e-3, (n, relerr(gr, g_o[n]))
