@@ -267,3 +267,12 @@ def test_other_omic_group_counts_and_tiny_bags(dev, kind, n_groups):
         # co-attention module alone agrees to 1.5e-5 at 16 queries, tests/gpu_diag_nq16.py); everything else is < 1e-3
         assert err < 1e-2, (n, err)
     print(f"worst gradient error [{kind}, {n_groups} groups]: {worst[0]:.2e} at {worst[1]}")
+
+
+def test_more_than_16_omic_groups_fails_loudly(dev):
+    """The omic queries are the 16 columns of one MFMA block: 17 groups is refused with a message, never mis-computed."""
+    omic_sizes = [8] * 17
+    model = MultimodalCoAttentionTransformer(omic_sizes=omic_sizes).to(dev).eval()
+    wsi = torch.randn(64, 1024, device=dev)
+    with pytest.raises(RuntimeError, match="omic queries must be in 1..16"):
+        model(wsi=wsi, omics=[torch.randn(8, device=dev) for _ in omic_sizes])
