@@ -97,16 +97,17 @@ def test_model_bf16_bag_within_north_star(dev, kind):
 
 
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])
-def test_window_equals_per_slide(dev, kind):
-    """One ragged window launch == the reference's slide-by-slide loop (values and summed grads)."""
+@pytest.mark.parametrize("lengths", [[300, 1, 2048, 77], [30000] + [40] * 15 + [7] * 16], ids=["mixed", "one_giant_31_tiny"])
+def test_window_equals_per_slide(dev, kind, lengths):
+    """One ragged window launch == the reference's slide-by-slide loop (values and summed grads); the second window is
+    the work plan's worst case: one 30 000-patch slide owns almost every workgroup, 31 slides of 40 / 7 patches one each."""
     omic_sizes, seed = [64, 100, 256, 31, 8, 300], 777
-    lengths = [300, 1, 2048, 77]
     model, _ = build(kind, omic_sizes, seed, dev)
     g = syn.rng(seed)
     wsis = [syn.normal(g, (m, 1024)).to(dev) for m in lengths]
     omics = [[syn.normal(g, (s,)).to(dev) for s in omic_sizes] for _ in lengths]
-    labels = torch.tensor([0, 1, 2, 3], device=dev)
-    cens = torch.tensor([0., 1., 0., 1.], device=dev)
+    labels = (torch.arange(len(lengths)) % 4).to(dev)
+    cens = (torch.arange(len(lengths)) % 2).float().to(dev)
     bags = BagBatch.from_list(wsis)
     om_w = [torch.stack([omics[b][i] for b in range(len(lengths))]) for i in range(len(omic_sizes))]
     hz_w, sv_w, y_w, att_w = model.forward_window(bags, om_w, inference=True)
