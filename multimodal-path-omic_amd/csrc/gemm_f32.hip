@@ -23,63 +23,13 @@
 
 #include "mpo_common.h"
 #include "mpo_kernels.h"
+#include "gemm_f32_gate.h"
 
 namespace {
 
 constexpr int BM = 32, BN = 32, KC = 256, LDK = KC + 8, LDM = 36;
 constexpr int IMG_FLOATS = KC * LDM > BM * LDK ? KC * LDM : BM * LDK;
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case MPO_ACT_RELU: return fmaxf(v, 0.f);
-        case MPO_ACT_ELU: return v > 0.f ? v : expm1f(v);
-        case MPO_ACT_TANH: return tanhf(v);
-        case MPO_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
-        default: return v;
-    }
-}
-
-struct GateFn {
-    const float* g;
-    int mode;
-    float p, inv_keep;
-    uint64_t seed, off;
-    __device__ __forceinline__ float operator()(float gv, size_t idx) const {
-        switch (mode) {
-            case MPO_GATE_RELU: return gv > 0.f ? inv_keep : 0.f;
-            case MPO_GATE_ELU: return gv > 0.f ? 1.0f : gv + 1.0f;
-            case MPO_GATE_TANH: {
-                if (gv == 0.f) return p > 0.f ? 0.f : 1.0f;
-                const float t = gv * (1.0f - p);
-                return (1.0f - t * t) * inv_keep;
-            }
-            case MPO_GATE_SIGMOID: {
-                if (gv == 0.f) return 0.f;
-                const float sg = gv * (1.0f - p);
-                return sg * (1.0f - sg) * inv_keep;
-            }
-            case MPO_GATE_RNG: return dropout_keep(seed, off, idx, p, inv_keep);
-            case MPO_GATE_ELU_ADROP: {
-                if (p <= 0.f) return gv > 0.f ? 1.0f : gv + 1.0f;
-                if (dropout_keep(seed, off, idx, p, 1.0f) == 0.f) return 0.f;
-                const float a = alpha_drop_a(p), u = (gv - alpha_drop_b(p)) / a;
-                return a * (u > 0.f ? 1.0f : u + 1.0f);
-            }
-            case MPO_GATE_MUL: return gv;
-            default: return 1.0f;
-        }
-    }
-    // same result as operator() when the element's Philox word is already at hand (one draw serves four elements)
-    __device__ __forceinline__ float with_word(float gv, uint32_t w) const {
-        const bool keep = (float)(w >> 8) * (1.0f / 16777216.0f) >= p;
-        if (mode == MPO_GATE_RNG) return keep ? inv_keep : 0.f;
-        if (p <= 0.f) return gv > 0.f ? 1.0f : gv + 1.0f;                    // MPO_GATE_ELU_ADROP
-        if (!keep) return 0.f;
-        const float a = alpha_drop_a(p), u = (gv - alpha_drop_b(p)) / a;
-        return a * (u > 0.f ? 1.0f : u + 1.0f);
-    }
-    __device__ __forceinline__ bool draws() const { return mode == MPO_GATE_RNG || mode == MPO_GATE_ELU_ADROP; }
-};
 
 // One operand tile (32 rows x KC k) in flight in registers: 8 float4 per thread.
 template <bool KCONTIG>
@@ -185,27 +135,6 @@ void gemm_f32_kernel(GemmArgs g) {
 }
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256)
-void gemm_f32_group_kernel(GemmGroup grp) {
-    __shared__ GemmLds lds;
-    gemm_f32_body<A_KC, B_KC>(grp.g[blockIdx.z], lds);
-}
-
-// members of DIFFERENT operand layouts in one launch (GemmArgs::layout): a layer's dx and dW products, which
-// both hang off the same dy, cost one dispatch instead of two on the latency-bound token tail
-__global__ __launch_bounds__(256)
-void gemm_f32_mixed_kernel(GemmGroup grp) {
-    __shared__ GemmLds lds;
-    const GemmArgs& g = grp.g[blockIdx.z];
-    switch (g.layout) {
-        case 3: gemm_f32_body<true, true>(g, lds); break;
-        case 2: gemm_f32_body<true, false>(g, lds); break;
-        case 1: gemm_f32_body<false, true>(g, lds); break;
-        default: gemm_f32_body<false, false>(g, lds); break;
-    }
-}
-
-template <bool A_KC, bool B_KC>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, GemmLds& lds) {
     if ((int)blockIdx.y * BM >= g.M || (int)blockIdx.x * BN >= g.N) return;      // grouped launch: grid is the max extent
     float* As = lds.As;
@@ -291,205 +220,19 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, GemmLds& lds) {
 
 
 // ------------------------------------------------------------------------------------------------ direct variant
-// The token tail's products are ~25 MFLOP each and sit in dependent chains of ~100 launches per window: what
-// counts is the latency of ONE product, not throughput.  This variant drops the LDS staging round trip:
-//   * 16 x 16 outputs per workgroup (3-4x more workgroups than the staged kernel: every CU gets one),
-//   * the four waves split K; each lane loads its MFMA fragments straight from global/L2 (a float4 per four
-//     MFMAs when k is contiguous, four strided scalars otherwise), up to 12 k-blocks in flight at once,
-//   * one LDS exchange at the end sums the four partial tiles; thread t then owns output element t.
-// Measured r01 in a HIP graph: 192x256x256 6.8 us (staged) -> see DESIGN.md.
-constexpr int DB = 16;                 // tile edge
-constexpr int DMAXB = 8;               // k-blocks (of 16) a wave keeps in flight at most (12 made the compiler serialise the loads)
-
-template <bool KC>
-__device__ __forceinline__ f32x4 direct_frag(const float* __restrict__ p, int ld, int mn, int mn_lim, int k0, int k_lim, bool vec_ok) {
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (mn >= mn_lim || k0 >= k_lim) return r;
-    if (KC) {
-        const float* q = p + (size_t)mn * ld + k0;
-        if (vec_ok && k0 + 3 < k_lim) return *reinterpret_cast<const f32x4*>(q);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) r[j] = q[j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) r[j] = p[(size_t)(k0 + j) * ld + mn];
-    }
-    return r;
-}
-// gate factors for the four elements of one fragment; gv holds the gate tensor's values there (loaded WITH the
-// fragment, so the gate never adds a dependent memory round trip)
-template <bool KC>
-__device__ __forceinline__ void direct_gate(f32x4& v, const f32x4& gv, const GateFn& gf, int ld, int mn, int mn_lim, int k0, int k_lim) {
-    if (mn >= mn_lim || k0 >= k_lim) return;
-    if (KC) {
-        const size_t idx0 = (size_t)mn * ld + k0;
-        if (gf.draws() && (idx0 & 3) == 0) {
-            const uint64_t ctr = gf.off + (idx0 >> 2);
-            const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
-            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf.with_word(gv[j], w[j]);
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf(gv[j], idx0 + j);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf(gv[j], (size_t)(k0 + j) * ld + mn);
-    }
-}
-// Row-contiguous operand with a drawing gate: element (k0 + j, mn) has index (k0 + j) * ld + mn, so the four lanes of
-// a quad (mn = 4q .. 4q+3) share ONE Philox counter per j.  Lane s of the quad draws the counter of j = s and the
-// quad transposes the 4 x 4 words with four quad shuffles: one draw per lane and fragment instead of four.
-// Every lane of the wave must call this (no early exit before the shuffles).
-__device__ __forceinline__ void direct_gate_rows_quad(f32x4& v, const f32x4& gv, const GateFn& gf, int ld, int mn, int mn_lim,
-                                                      int k0, int k_lim, int lane) {
-    const int lq = lane & 3;
-    const size_t idx_own = (size_t)(k0 + lq) * ld + (mn & ~3);           // first element of the quad's group for j = lq
-    const uint64_t ctr = gf.off + (idx_own >> 2);
-    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
-    const uint32_t own[4] = {r.x, r.y, r.z, r.w};
-    uint32_t w[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int pick = lq ^ t;                                         // word wanted by the lane this value goes to
-        const uint32_t send = pick == 0 ? own[0] : pick == 1 ? own[1] : pick == 2 ? own[2] : own[3];
-        const uint32_t got = (uint32_t)__shfl_xor((int)send, t);        // from lane lq ^ t: its word for lane lq
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (j == (lq ^ t)) w[j] = got;       // that lane drew element j = lq ^ t
-    }
-    if (mn >= mn_lim) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf.with_word(gv[j], w[j]);
-}
-
-// NB k-blocks of one wave: every load is issued before the first MFMA (out-of-range fragments are zero-filled,
-// so the count can be a compile-time constant and nothing is predicated)
-template <bool A_KC, bool B_KC>
-struct DirectCtx {
-    const GemmArgs& g;
-    const GateFn& gf;
-    int m, n, kq, kend, lane;
-    bool a_vec, b_vec, gated, want_bsum;
-    template <int NB>
-    __device__ __forceinline__ void chunk(int kbase, f32x4& acc0, f32x4& acc1, float& bsum) const {
-        f32x4 a[NB], b[NB], gv[NB];
-        const bool gate_tensor = gated && gf.g != nullptr;
-        const bool quad_draw = gf.draws() && (g.lda & 3) == 0;           // (m0 is a multiple of 16: quads are aligned)
-        const bool g_vec = a_vec && (reinterpret_cast<uintptr_t>(gf.g) & 15) == 0;
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int k0 = kbase + 16 * u + 4 * kq;
-            a[u] = direct_frag<A_KC>(g.A, g.lda, m, g.M, k0, kend, a_vec);
-            b[u] = direct_frag<B_KC>(g.B, g.ldb, n, g.N, k0, kend, b_vec);
-            gv[u] = gate_tensor ? direct_frag<A_KC>(gf.g, g.lda, m, g.M, k0, kend, g_vec) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            if (gated) {
-                if (!A_KC && quad_draw) direct_gate_rows_quad(a[u], gv[u], gf, g.lda, m, g.M, kbase + 16 * u + 4 * kq, kend, lane);
-                else direct_gate<A_KC>(a[u], gv[u], gf, g.lda, m, g.M, kbase + 16 * u + 4 * kq, kend);
-            }
-            if (want_bsum) bsum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0], b[u][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1], b[u][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][2], b[u][2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][3], b[u][3], acc1, 0, 0, 0);
-        }
-    }
-};
-
-struct DirectLds {
-    float part[4][256];
-    float bsum[4][16];
-};
-
-template <bool A_KC, bool B_KC, int NBMAX>
-__device__ __forceinline__ void gemm_f32_direct_body(const GemmArgs& g, DirectLds& lds) {
-    if ((int)blockIdx.y * DB >= g.M || (int)blockIdx.x * DB >= g.N) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * DB, n0 = blockIdx.x * DB;
-    const int i16 = lane & 15, kq = lane >> 4;
-    const bool a_vec = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
-    const bool b_vec = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
-    GateFn gf;
-    gf.g = g.gate; gf.mode = g.gate_mode; gf.p = g.gate_p; gf.seed = g.gate_seed;
-    gf.off = epoch_offset(g.gate_off, g.rng_epoch);
-    gf.inv_keep = g.gate_p > 0.f ? 1.0f / (1.0f - g.gate_p) : 1.0f;
-    const bool gated = g.gate_mode != MPO_GATE_NONE;
-    const bool want_bsum = g.bias_grad != nullptr && blockIdx.x == 0;
-
-    const int kw = ((g.K + 63) >> 6) << 4;                      // k per wave, a multiple of 16
-    const int kbeg = wave * kw, kend = min(g.K, kbeg + kw);
-    const int nkb = kend > kbeg ? (kend - kbeg + 15) >> 4 : 0;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    float bsum = 0.f;
-    const int nkb_all = kw >> 4;                                // wave-uniform AND workgroup-uniform block count
-    DirectCtx<A_KC, B_KC> cx{g, gf, m0 + i16, n0 + i16, kq, kend, lane, a_vec, b_vec, gated, want_bsum};
-    // NBMAX is picked by the host from the largest K of the launch (4: K <= 256, 8: K <= 512, else 12): the register
-    // footprint -- hence how many workgroups a CU holds -- follows the blocks kept in flight
-    for (int kb0 = 0; kb0 < nkb_all; kb0 += NBMAX) cx.template chunk<NBMAX>(kbeg + 16 * kb0, acc0, acc1, bsum);
-    (void)nkb;
-    // ---- exchange: lane holds D[row = 4*kq + r][col = i16]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lds.part[wave][(4 * kq + r) * 16 + i16] = acc0[r] + acc1[r];
-    if (want_bsum) {
-        bsum += __shfl_xor(bsum, 16);
-        bsum += __shfl_xor(bsum, 32);
-        if (lane < 16) lds.bsum[wave][lane] = bsum;
-    }
-    __syncthreads();
-    const int row = tid >> 4, col = tid & 15;
-    const int m = m0 + row, n = n0 + col;
-    if (m < g.M && n < g.N) {
-        float v = (lds.part[0][tid] + lds.part[1][tid]) + (lds.part[2][tid] + lds.part[3][tid]);
-        v = (v + (g.bias ? g.bias[n] : 0.f)) * g.alpha;
-        v = apply_act(v, g.act);
-        const size_t o = (size_t)m * g.ldc + n;
-        if (g.drop_p > 0.f) {
-            const unsigned long long doff = epoch_offset(g.drop_off, g.rng_epoch);
-            if (g.alpha_dropout) {
-                const bool keep = dropout_keep(g.drop_seed, doff, o, g.drop_p, 1.0f) != 0.f;
-                v = alpha_drop_a(g.drop_p) * (keep ? v : kAlphaPrime) + alpha_drop_b(g.drop_p);
-            } else {
-                v *= dropout_keep(g.drop_seed, doff, o, g.drop_p, 1.0f / (1.0f - g.drop_p));
-            }
-        }
-        if (g.mask) v *= g.mask[o];
-        if (g.residual) v += g.residual[o];
-        if (g.accumulate) v += g.C[o];
-        g.C[o] = v;
-    }
-    if (want_bsum && tid < DB && m0 + tid < g.M)
-        g.bias_grad[m0 + tid] = (lds.bsum[0][tid] + lds.bsum[1][tid]) + (lds.bsum[2][tid] + lds.bsum[3][tid]);
-}
-
-template <int NBMAX>
-__global__ __launch_bounds__(256)
-void gemm_f32_direct_kernel(GemmGroup grp) {
-    __shared__ DirectLds lds;
-    const GemmArgs& g = grp.g[blockIdx.z];
-    switch (g.layout) {
-        case 3: gemm_f32_direct_body<true, true, NBMAX>(g, lds); break;
-        case 2: gemm_f32_direct_body<true, false, NBMAX>(g, lds); break;
-        case 1: gemm_f32_direct_body<false, true, NBMAX>(g, lds); break;
-        default: gemm_f32_direct_body<false, false, NBMAX>(g, lds); break;
-    }
-}
-template <bool A_KC, bool B_KC, int NBMAX>
-__global__ __launch_bounds__(256)
-void gemm_f32_direct_single_kernel(GemmArgs g) {
-    __shared__ DirectLds lds;
-    gemm_f32_direct_body<A_KC, B_KC, NBMAX>(g, lds);
-}
-inline int direct_nbmax(int k) { return k <= 256 ? 4 : k <= 512 ? 8 : DMAXB; }
-template <bool A_KC, bool B_KC>
-void launch_direct_single(const GemmArgs& g, dim3 grid, hipStream_t stream) {
-    switch (direct_nbmax(g.K)) {
-        case 4: gemm_f32_direct_single_kernel<A_KC, B_KC, 4><<<grid, 256, 0, stream>>>(g); break;
-        case 8: gemm_f32_direct_single_kernel<A_KC, B_KC, 8><<<grid, 256, 0, stream>>>(g); break;
-        default: gemm_f32_direct_single_kernel<A_KC, B_KC, DMAXB><<<grid, 256, 0, stream>>>(g); break;
-    }
+// (templates in gemm_f32_direct.h, instantiated per NBMAX in their own translation units)
+constexpr int DB = 16;
+constexpr int DMAXB = 8;
+}  // namespace
+void mpo_direct_single_nb4(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream);
+void mpo_direct_single_nb8(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream);
+void mpo_direct_group_nb4(const GemmGroup& grp, dim3 grid, hipStream_t stream);
+void mpo_direct_group_nb8(const GemmGroup& grp, dim3 grid, hipStream_t stream);
+namespace {
+inline int direct_nbmax(int k) { return k <= 256 ? 4 : DMAXB; }
+void launch_direct_single(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream) {
+    if (direct_nbmax(g.K) == 4) mpo_direct_single_nb4(g, layout, grid, stream);
+    else mpo_direct_single_nb8(g, layout, grid, stream);
 }
 void launch_direct_group(const GemmGroup& grp, dim3 grid, hipStream_t stream) {
     int kmax = 0;
@@ -497,11 +240,8 @@ void launch_direct_group(const GemmGroup& grp, dim3 grid, hipStream_t stream) {
     // a launch that fills the chip several times over is throughput-bound: the 4-block variant's smaller register
     // footprint (4 instead of 2 workgroups per CU) then beats having all of K in flight at once
     const size_t wgs = (size_t)grid.x * grid.y * grid.z;
-    switch (wgs > 1024 ? 4 : direct_nbmax(kmax)) {
-        case 4: gemm_f32_direct_kernel<4><<<grid, 256, 0, stream>>>(grp); break;
-        case 8: gemm_f32_direct_kernel<8><<<grid, 256, 0, stream>>>(grp); break;
-        default: gemm_f32_direct_kernel<DMAXB><<<grid, 256, 0, stream>>>(grp); break;
-    }
+    if (wgs > 1024 || direct_nbmax(kmax) == 4) mpo_direct_group_nb4(grp, grid, stream);
+    else mpo_direct_group_nb8(grp, grid, stream);
 }
 
 // MPO_GEMM_STAGED=1 selects the LDS-staged kernels everywhere (A/B comparison, debugging)
@@ -537,10 +277,7 @@ int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream) {
     MPO_CHECK(g.K > 0, "gemm: K must be positive (got %d)", g.K);
     if (use_direct()) {
         dim3 dgrid((g.N + DB - 1) / DB, (g.M + DB - 1) / DB);
-        if (a_kc && b_kc) launch_direct_single<true, true>(g, dgrid, stream);
-        else if (a_kc && !b_kc) launch_direct_single<true, false>(g, dgrid, stream);
-        else if (!a_kc && b_kc) launch_direct_single<false, true>(g, dgrid, stream);
-        else launch_direct_single<false, false>(g, dgrid, stream);
+        launch_direct_single(g, 2 * (a_kc ? 1 : 0) + (b_kc ? 1 : 0), dgrid, stream);
         MPO_LAUNCH_CHECK();
         return 0;
     }
@@ -570,12 +307,9 @@ int mpo_launch_gemm_group(const GemmGroup& grp, int a_kc, int b_kc, hipStream_t 
         MPO_LAUNCH_CHECK();
         return 0;
     }
-    dim3 grid((nx + BN - 1) / BN, (mx + BM - 1) / BM, grp.n);
-    if (a_kc && b_kc) gemm_f32_group_kernel<true, true><<<grid, 256, 0, stream>>>(grp);
-    else if (a_kc && !b_kc) gemm_f32_group_kernel<true, false><<<grid, 256, 0, stream>>>(grp);
-    else if (!a_kc && b_kc) gemm_f32_group_kernel<false, true><<<grid, 256, 0, stream>>>(grp);
-    else gemm_f32_group_kernel<false, false><<<grid, 256, 0, stream>>>(grp);
-    MPO_LAUNCH_CHECK();
+    // staged A/B path: one launch per member (the grouped staged kernels were dropped: 70 s of compile time for a debug switch)
+    for (int i = 0; i < grp.n; ++i)
+        if (int rc = mpo_launch_gemm(grp.g[i], a_kc, b_kc, stream)) return rc;
     return 0;
 }
 
@@ -595,9 +329,8 @@ int mpo_launch_gemm_mixed(const GemmGroup& grp, hipStream_t stream) {
         MPO_LAUNCH_CHECK();
         return 0;
     }
-    dim3 grid((nx + BN - 1) / BN, (mx + BM - 1) / BM, grp.n);
-    gemm_f32_mixed_kernel<<<grid, 256, 0, stream>>>(grp);
-    MPO_LAUNCH_CHECK();
+    for (int i = 0; i < grp.n; ++i)
+        if (int rc = mpo_launch_gemm(grp.g[i], grp.g[i].layout >> 1, grp.g[i].layout & 1, stream)) return rc;
     return 0;
 }
 
