@@ -22,12 +22,23 @@
 
 namespace {
 
+// (a native vector, not HIP's uint4 struct: arrays of the struct stayed in scratch memory -- every staged chunk went
+//  global -> wait -> scratch -> LDS, which serialised the whole pipeline)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Diagnostic builds only (tests/gpu_probe_keyproj_variants.py): bit 0 drops the stores, bit 1 the LDS reads + MFMAs,
+// bit 2 the global loads.  The product is built with 0.
+#ifndef KP_VARIANT
+#define KP_VARIANT 0
+#endif
 constexpr int KP_E = 256;
 constexpr int KP_WAVES = 8;
 constexpr int KP_THREADS = KP_WAVES * 64;
+constexpr int KP_NCT = KP_E / (16 * KP_WAVES);         // 16-column tiles a wave owns
+constexpr int KP_CHUNKS = kTileRows * 32 / KP_THREADS;  // 16-byte chunks of a tile each thread stages
 
 __global__ __launch_bounds__(KP_THREADS, 1)
-void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-byte chunks */, const float* __restrict__ w,
+void key_proj_kernel(const u32x4* __restrict__ hbag /* bf16 [rows][256] as 16-byte chunks */, const float* __restrict__ w,
                      const float* __restrict__ bias, float* __restrict__ kout, int rows) {
     using G = TileGeom<KP_E>;
     __shared__ __attribute__((aligned(16))) char img[2][G::TILEB];
@@ -35,14 +46,14 @@ void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-by
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
-    const int n0 = 32 * wave;
+    const int n0 = 16 * KP_NCT * wave;
 
     // this wave's weight slice as MFMA B fragments: lane supplies W[n0 + 16 ct + c16][32 s + 8 g .. + 7], split in three
-    bf16x8 whi[2][G::KS], wmid[2][G::KS], wlo[2][G::KS];
+    bf16x8 whi[KP_NCT][G::KS], wmid[KP_NCT][G::KS], wlo[KP_NCT][G::KS];
     // (the weight fragment is the MFMA's A operand and the H rows its B operand: D[n = 4g + r][patch = c16], so a lane ends
     //  up with FOUR CONSECUTIVE OUTPUT COLUMNS of one patch row -- one 16-byte store instead of four 4-byte ones)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < KP_NCT; ++ct) {
         const float* wr = w + (size_t)(n0 + 16 * ct + c16) * KP_E;
 #pragma unroll
         for (int s = 0; s < G::KS; ++s) {
@@ -66,43 +77,42 @@ void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-by
 
     // cooperative staging: the tile is 32 rows x 32 chunks of 16 bytes; thread t moves chunks t and t + 512
     const int ntiles = (rows + kTileRows - 1) / kTileRows;
-    static_assert(2 * KP_THREADS == kTileRows * 32, "two 16-byte chunks per thread per tile");
     // TWO tiles are in flight in registers (sa: the next tile, sb: the one after): one tile of MFMA work (~0.7 us) does
     // not cover an HBM round trip, and the 8 waves of the workgroup advance in lockstep behind one barrier per tile
-    uint4 sa[2], sb[2];
-    auto fetch = [&](uint4 (&st)[2], int tile) {
+    u32x4 sa[KP_CHUNKS], sb[KP_CHUNKS];
+    auto fetch = [&](u32x4 (&st)[KP_CHUNKS], int tile) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < KP_CHUNKS; ++i) {
             const int ci = tid + i * KP_THREADS;
             const int r = ci >> 5, cc = ci & 31;
             int row = tile * kTileRows + r;
             row = row < rows ? row : rows - 1;                               // clamp: finite data, stores are guarded
-            st[i] = hbag[(size_t)row * 32 + cc];
+            if ((KP_VARIANT & 4) == 0 || rows < 0) st[i] = hbag[(size_t)row * 32 + cc];
         }
     };
-    auto stage = [&](const uint4 (&st)[2], char* image) {
+    auto stage = [&](const u32x4 (&st)[KP_CHUNKS], char* image) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < KP_CHUNKS; ++i) {
             const int ci = tid + i * KP_THREADS;
             const int r = ci >> 5, cc = ci & 31;
-            *reinterpret_cast<uint4*>(image + r * G::ROWB + ((cc ^ ((r & 7) << 1)) << 4)) = st[i];
+            *reinterpret_cast<u32x4*>(image + r * G::ROWB + ((cc ^ ((r & 7) << 1)) << 4)) = st[i];
         }
     };
     auto compute = [&](const char* image, int tile, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;       // FULL: all 32 rows exist -> unconditional stores
-        f32x4 acc[2][2];
+        f32x4 acc[2][KP_NCT];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < KP_NCT; ++ct) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + n0 + 16 * ct + 4 * g);   // columns n0 + 16 ct + 4g .. + 3
             acc[0][ct] = b4;
             acc[1][ct] = b4;
         }
 #pragma unroll
-        for (int s = 0; s < G::KS; ++s) {
+        for (int s = 0; s < ((KP_VARIANT & 2) ? 0 : G::KS); ++s) {
             const bf16x8 a0 = row_frag<KP_E>(image, 0, s, lane);
             const bf16x8 a1 = row_frag<KP_E>(image, 1, s, lane);
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
+            for (int ct = 0; ct < KP_NCT; ++ct) {
                 acc[0][ct] = mfma_bf16(whi[ct][s], a0, acc[0][ct]);
                 acc[1][ct] = mfma_bf16(whi[ct][s], a1, acc[1][ct]);
                 acc[0][ct] = mfma_bf16(wmid[ct][s], a0, acc[0][ct]);
@@ -116,10 +126,10 @@ void key_proj_kernel(const uint4* __restrict__ hbag /* bf16 [rows][256] as 16-by
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             const int row = row0 + 16 * pt + c16;
-            if (FULL || row < rows) {
+            if (((KP_VARIANT & 1) == 0 || rows < 0) && (FULL || row < rows)) {
                 float* o = kout + (size_t)row * KP_E + n0 + 4 * g;
-                *reinterpret_cast<f32x4*>(o) = acc[pt][0];
-                *reinterpret_cast<f32x4*>(o + 16) = acc[pt][1];
+#pragma unroll
+                for (int ct = 0; ct < KP_NCT; ++ct) *reinterpret_cast<f32x4*>(o + 16 * ct) = acc[pt][ct];
             }
         }
     };
@@ -171,7 +181,7 @@ int mpo_launch_key_proj(const void* hbag_bf16, const float* w, const float* bias
               "key projection: bag, weight, bias and output must be 16-byte aligned");
     const int ntiles = (rows + kTileRows - 1) / kTileRows;
     const int grid = ntiles < 256 ? ntiles : 256;                            // one persistent workgroup per CU
-    key_proj_kernel<<<grid, KP_THREADS, 0, stream>>>(static_cast<const uint4*>(hbag_bf16), w, bias, kout, rows);
+    key_proj_kernel<<<grid, KP_THREADS, 0, stream>>>(static_cast<const u32x4*>(hbag_bf16), w, bias, kout, rows);
     MPO_LAUNCH_CHECK();
     return 0;
 }
