@@ -13,6 +13,8 @@
 //   map kernels  : gated softmax statistics / apply (+ dropout) / backward.
 // The same MFMA orientation rules as K1 apply (query index on the MFMA column).  A fully fused K2
 // (in-kernel K projection, one pass) is the planned successor; this form is parity-complete.
+#include <type_traits>
+
 #include "coattn_tile.h"
 #include "mpo_kernels.h"
 
@@ -459,8 +461,25 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
     char* dslide = reinterpret_cast<char*>(dk) + (size_t)sg.row_begin * E_ * (OUT_BF16 ? 2 : 4);
     // step st covers rows  tile(st >> 1) + 16 (st & 1);  the K rows of the NEXT step travel in registers meanwhile
     auto step_row = [&](int st) { return sg.r0 + kTileRows * (wave + (st >> 1) * 4) + HR * (st & 1); };
+    const int n_steps = 2 * sg.n_my;
+    // Everything a step needs from memory is loaded ONE STEP AHEAD, the two map columns first and the K rows after them,
+    // with clamped addresses instead of predicates.  gfx950 counts loads and stores in one in-order counter: loading the
+    // map values after the K prefetch (as the first version did) made their wait a wait for the whole prefetch, i.e.
+    // load -> compute -> store with nothing overlapped.
     f32x4 kv[NCH];
-    auto fetch = [&](int row0) {
+    float wan[4], wbn[4];
+    auto fetch = [&](int st) {
+        st = st < n_steps ? st : n_steps - 1;
+        const int row0 = step_row(st);
+        int mrow = row0 + c16;
+        mrow = mrow < sg.m_rows ? mrow : sg.m_rows - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qq = 4 * g + j;
+            const int qc = qq < n_q ? qq : n_q - 1;
+            wan[j] = w1b[(size_t)qc * sg.m_rows + mrow];
+            wbn[j] = w2b[(size_t)qc * sg.m_rows + mrow];
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ci = i * 64 + lane;
@@ -470,13 +489,20 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
             kv[i] = *reinterpret_cast<const f32x4*>(kslide + (size_t)grow * E_ + cc * 4);
         }
     };
-    const int n_steps = 2 * sg.n_my;
     static_assert(CH_PER_ROW <= 64 && 64 % CH_PER_ROW == 0, "copy-out: a lane keeps one 4-column chunk");
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};                       // column sums of the rows this lane copies out
-    if (n_steps > 0) fetch(step_row(0));
-    for (int st = 0; st < n_steps; ++st) {
+    auto step = [&](int st, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;        // all HR rows exist: nothing in the step is predicated
         const int row0 = step_row(st);
-        const int nvalid = max(0, min(HR, sg.r1 - row0));
+        const int nvalid = FULL ? HR : max(0, min(HR, sg.r1 - row0));
+        const int row = c16;
+        float wa[8], wb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool live = row < nvalid && 4 * g + (j & 3) < n_q && j < 4;   // k-slots 4..7 unused (zero)
+            wa[j] = live ? wan[j & 3] : 0.f;
+            wb[j] = live ? wbn[j & 3] : 0.f;
+        }
         // stage K (fp32) into the image, same chunk swizzle as the output image
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -484,20 +510,10 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
             const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
             *reinterpret_cast<f32x4*>(img + r * (E_ * 4) + ((cc ^ ((r & 7) << 1)) << 4)) = kv[i];
         }
-        if (st + 1 < n_steps) fetch(step_row(st + 1));
+        fetch(st + 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (nvalid > 0) {
-            const int row = c16;
-            const bool ok = row < nvalid;
-            float wa[8], wb[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int qq = 4 * g + (j & 3);
-                const bool live = ok && qq < n_q && j < 4;
-                wa[j] = live ? w1b[(size_t)qq * sg.m_rows + row0 + row] : 0.f;
-                wb[j] = live ? w2b[(size_t)qq * sg.m_rows + row0 + row] : 0.f;
-            }
+        if (FULL || nvalid > 0) {
             bf16x8 wah, wal, wbh, wbl;
             pack_hi_lo(wa, wah, wal);
             pack_hi_lo(wb, wbh, wbl);
@@ -531,7 +547,7 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
             const int ci = i * 64 + lane;
             const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
             const f32x4 v = *reinterpret_cast<const f32x4*>(img + r * (E_ * 4) + ((cc ^ ((r & 7) << 1)) << 4));
-            if (r < nvalid) {
+            if (FULL || r < nvalid) {
                 if constexpr (OUT_BF16) {
                     bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                     *reinterpret_cast<bf16x4*>(dslide + ((size_t)(row0 + r) * E_ + cc * 4) * 2) = o;
@@ -543,6 +559,24 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    // hipcc's wait counts must hold on every path into a wait, so (a) full steps -- no predicated store, the count of
+    // stores between a prefetch and its use is a constant -- run in their own loop, the ragged last steps after it, and
+    // (b) the first step is peeled: the loop's entry edge (prefetch loads youngest) and its back edge (a step's stores
+    // younger than the prefetch) would otherwise be joined conservatively, i.e. every step would wait for the previous
+    // step's STORES to be acknowledged before staging the next rows.
+    if (n_steps > 0) {
+        using Full = std::integral_constant<bool, true>;
+        using Guarded = std::integral_constant<bool, false>;
+        int n_full = 0;
+        while (n_full < n_steps && step_row(n_full) + HR <= sg.r1) ++n_full;
+        fetch(0);
+        int st = 0;
+        if (n_full > 0) {
+            step(0, Full());
+            for (st = 1; st < n_full; ++st) step(st, Full());
+        }
+        for (; st < n_steps; ++st) step(st, Guarded());
     }
     if (part_colsum != nullptr) {
         __syncthreads();

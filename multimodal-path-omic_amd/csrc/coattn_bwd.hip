@@ -15,6 +15,8 @@
 // as  dH^T[d][p] = Z^T[d][k] W^T[k][p]  with k running over (A rows | dS rows), so each lane owns
 // 4 consecutive d of one patch; the tile's own LDS image is overwritten with dH and copied out
 // in whole rows.
+#include <type_traits>
+
 #include "coattn_tile.h"
 #include "mpo_kernels.h"
 
@@ -144,19 +146,47 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 
     Stage<E_, F32BAG> st0;
     Stage<E_, F32BAG> st1;
-    if (n_my > 0) {
-        st0.load(slide, r0 + kTileRows * wave, m_rows, 0, lane);
-        if constexpr (F32BAG) st1.load(slide, r0 + kTileRows * wave, m_rows, 1, lane);
-    }
-    for (int it = 0; it < n_my; ++it) {
+    // One tile.  gfx950 counts loads and stores in ONE in-order counter and hipcc's wait counts must hold on every path
+    // into a wait, so the step is written for constant counts: FULL tiles (all 32 rows exist) have no predicated load or
+    // store at all, every global load of a step -- the map-gradient values first, the next tile's rows after them -- is
+    // issued before the compute with clamped addresses (rows are clamped to the slide, so the prefetch past the last
+    // tile re-reads valid rows), and the caller peels the first step so that the loop's entry and back edges agree.
+    // Before: every step drained the counter (vmcnt(0)), i.e. waited for the previous tile's dH stores to be
+    // acknowledged before staging the next rows.
+    auto tile_step = [&](int it, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const int trow = r0 + kTileRows * (wave + it * WAVES);
-        const int nvalid = min(kTileRows, r1 - trow);
+        const int nvalid = FULL ? kTileRows : min(kTileRows, r1 - trow);
         st0.store(thi, tlo, 0, lane);
         if constexpr (F32BAG) st1.store(thi, tlo, 1, lane);
-        if (it + 1 < n_my) {
-            st0.load(slide, trow + kTileRows * WAVES, m_rows, 0, lane);
-            if constexpr (F32BAG) st1.load(slide, trow + kTileRows * WAVES, m_rows, 1, lane);
+        // map gradient of this tile's rows in the patch-on-lane orientation (and query-on-lane for the fp32 bag)
+        float dap[2][4], daq[2][4];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dap[pt][r] = daq[pt][r] = 0.f;
+        if (da_b != nullptr) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    {
+                        const int row = 16 * pt + c16, qq = 4 * g + r;
+                        const int rc = min(trow + row, m_rows - 1), qc = min(qq, n_q - 1);
+                        const float v = da_b[(size_t)qc * m_rows + rc];
+                        dap[pt][r] = ((FULL || row < nvalid) && qq < n_q) ? v : 0.f;
+                    }
+                    if constexpr (F32BAG) {
+                        const int row = 16 * pt + 4 * g + r;
+                        const int rc = min(trow + row, m_rows - 1), qc = min(c16, n_q - 1);
+                        const float v = da_b[(size_t)qc * m_rows + rc];
+                        daq[pt][r] = ((FULL || row < nvalid) && c16 < n_q) ? v : 0.f;
+                    }
+                }
+            }
         }
+        st0.load(slide, trow + kTileRows * WAVES, m_rows, 0, lane);
+        if constexpr (F32BAG) st1.load(slide, trow + kTileRows * WAVES, m_rows, 1, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -174,13 +204,12 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
     #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
                     const int row = 16 * pt + c16;
-                    const bool ok = row < nvalid;
+                    const bool ok = FULL || row < nvalid;
                     float w[8];
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int qq = 4 * g + r;
-                        float da = pt == 0 ? d0[r] : d1[r];
-                        if (da_b != nullptr && ok && qq < n_q) da += da_b[(size_t)qq * m_rows + trow + row];
+                        const float da = (pt == 0 ? d0[r] : d1[r]) + dap[pt][r];
                         const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_p[r]) : 0.f;
                         w[r] = a;
                         w[4 + r] = a * (da - del_p[r]);
@@ -215,9 +244,8 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
     #pragma unroll
                     for (int pt = 0; pt < 2; ++pt) {
                         const int row = 16 * pt + 4 * g + r;
-                        const bool ok = row < nvalid;
-                        float da = pt == 0 ? d0[r] : d1[r];
-                        if (da_b != nullptr && ok && c16 < n_q) da += da_b[(size_t)c16 * m_rows + trow + row];
+                        const bool ok = FULL || row < nvalid;
+                        const float da = (pt == 0 ? d0[r] : d1[r]) + daq[pt][r];
                         const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_q) : 0.f;
                         ds[4 * pt + r] = a * (da - del_q);
                     }
@@ -235,13 +263,11 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
     #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
                     const int row = 16 * pt + c16;
-                    const bool ok = row < nvalid;
+                    const bool ok = FULL || row < nvalid;
                     float w[8];
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int qq = 4 * g + r;
-                        float da = pt == 0 ? d0[r] : d1[r];
-                        if (da_b != nullptr && ok && qq < n_q) da += da_b[(size_t)qq * m_rows + trow + row];
+                        const float da = (pt == 0 ? d0[r] : d1[r]) + dap[pt][r];
                         const float a = ok ? __builtin_amdgcn_exp2f((pt == 0 ? s0[r] : s1[r]) - lse_p[r]) : 0.f;
                         w[r] = a;
                         w[4 + r] = a * (da - del_p[r]);
@@ -296,7 +322,7 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                 const int ci = i * 64 + lane;
                 const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(thi + r * (E_ * EB) + ((cc ^ ((r & 7) << 1)) << 4));
-                if (r < nvalid) {
+                if (FULL || r < nvalid) {
                     *reinterpret_cast<f32x4*>(dslide + ((size_t)(trow + r) * CH_PER_ROW + cc) * 16) = v;
                     if (part_colsum != nullptr) {
                         if constexpr (F32BAG) {
@@ -312,6 +338,20 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    if (n_my > 0) {
+        using Full = std::integral_constant<bool, true>;
+        using Guarded = std::integral_constant<bool, false>;
+        int n_full = 0;
+        while (n_full < n_my && r0 + kTileRows * (wave + n_full * WAVES) + kTileRows <= r1) ++n_full;
+        st0.load(slide, r0 + kTileRows * wave, m_rows, 0, lane);
+        if constexpr (F32BAG) st1.load(slide, r0 + kTileRows * wave, m_rows, 1, lane);
+        int it = 0;
+        if (n_full > 0) {
+            tile_step(0, Full());
+            for (it = 1; it < n_full; ++it) tile_step(it, Full());
+        }
+        for (; it < n_my; ++it) tile_step(it, Guarded());
     }
 
     // ---- merge the waves' dqk through LDS and write this workgroup's partial

@@ -15,9 +15,9 @@ _build = importlib.import_module("multimodal-path-omic_amd._build")
 ALLOWED = {
     "coattn_fwd_partial_kernelILi512ELb0": 1024,
     "coattn_fwd_partial_kernelILi512ELb1": 1024,
-    "coattn_bwd_kernelILi512ELb0": 1024,
+    "coattn_bwd_kernelILi512ELb0": 2048,
     "coattn_bwd_kernelILi512ELb1": 4096,
-    "coattn_bwd_kernelILi256ELb1": 512,
+    "coattn_bwd_kernelILi256ELb1": 1024,
     "key_proj_kernel": 32,
 }
 
