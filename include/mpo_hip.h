@@ -166,10 +166,24 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
                                 float* d_query, void* d_kbag, int dk_dtype, float* d_kbag_colsum /* nullable [embed] */,
-                                void* d_hbag,
+                                void* d_hbag /* nullable when d_ctx is given */,
+                                float* d_ctx /* nullable [n_slides*n_q][embed]: receives dL/d(A_drop V-side context); the
+                                                dH outer product is then left to mpo_nacagat_patch_grad() */,
                                 float* d_in_proj_weight, float* d_in_proj_bias,
                                 float* d_out_proj_weight, float* d_out_proj_bias, const mpo_bag_plan* plan /* nullable */,
                                 void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
+/* Patch-side gradient of K2 for a bf16 bag, one pass (ABI v7):
+ *   d_bag[m][e] = ( sum_q attn_map[q][m] d_ctx[q][e] + addend[m][e] ) * (hbag[m][e] > 0 ? relu_gate : 0)
+ * addend = d_kbag W_k (the caller's GEMM back through K = H W_k^T + b_k, models/blocks.py:151-166); hbag is the bag
+ * itself: for H = dropout(relu(.)) (models/nacagat/nacagat.py:20-25 via mcat.py:24-29) its sign is that layer's
+ * ReLU/dropout derivative, relu_gate = 1/(1-p) (0: no gating).  d_bag may alias addend.  d_bias (nullable, [embed])
+ * receives the column sums of d_bag = the bias gradient of the layer that produced the bag.
+ * workspace: mpo_nacagat_workspace_bytes() of the same geometry is enough. */
+int mpo_nacagat_patch_grad(const int32_t* cu_rows, int n_slides, int total_rows, int max_rows, int n_q, int embed,
+                           const float* attn_map, const float* d_ctx, const void* addend_bf16, const void* hbag_bf16,
+                           void* d_bag_bf16, float relu_gate, float* d_bias, const mpo_bag_plan* plan /* nullable */,
+                           void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ==== the 6 x d token tail.  Parameter and gradient tensors are passed as arrays of device pointers in
  * the order listed per entry (the reference's state_dict order); dropout streams are Philox counters

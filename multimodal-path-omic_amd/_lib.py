@@ -58,7 +58,8 @@ _SIGNATURES = {
                                            c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_nacagat_backward": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
                                             c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P,
-                                            _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                            _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_nacagat_patch_grad": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_size_t, _P]),
     "mpo_survival_head_forward": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "mpo_survival_head_backward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "mpo_ces_loss_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P]),

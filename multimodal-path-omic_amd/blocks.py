@@ -149,12 +149,12 @@ class PreGatingContextualAttention(nn.Module):
         nn.init.zeros_(self.in_proj_bias)
         nn.init.zeros_(self.out_proj.bias)
 
-    def forward_window(self, query: torch.Tensor, bags: BagBatch):
+    def forward_window(self, query: torch.Tensor, bags: BagBatch, bag_relu_gate: float = 0.0):
         n_slides, n_q, e = query.shape
         q2 = query.reshape(n_slides * n_q, e)
         q_proj, out, amap = ops.coattn_nacagat(q2, bags, self.in_proj_weight, self.in_proj_bias,
                                                self.out_proj.weight, self.out_proj.bias,
-                                               self.dropout if self.training else 0.0)
+                                               self.dropout if self.training else 0.0, bag_relu_gate)
         c = self.CAG(q2, q_proj)
         return (out + c).view(n_slides, n_q, e), bags.split_map(amap, n_q)
 

@@ -235,6 +235,147 @@ void bag_outer_kernel(const int* __restrict__ cu, const float* __restrict__ w1, 
     }
 }
 
+// ------------------------------------------------------------------ (iii'') patch-side gradient of K2 in one pass
+//   G[m][e] = ( sum_n W1[n][m] Z1[n][e]  +  ADD[m][e] ) * (H[m][e] > 0 ? gate : 0)          bf16 bag
+// with W1 = A_drop (ragged map), Z1 = dL/dctx, ADD = dK W_k from the library GEMM and H the bag itself
+// (H = dropout(relu(pre)): its sign is the ReLU/dropout derivative of the layer that produced the bag, gate = 1/(1-p)).
+// Replaces bag_outer + addmm's read-modify-write of dH + the element-wise derivative pass: one read of ADD and H,
+// one write of G (which may alias ADD), column sums of G (= that layer's bias gradient) on the way out.
+// The outer product is kept in fp32 in the LDS image until the sum is rounded once.
+template <int E_>
+__global__ __launch_bounds__(256, 1)
+void bag_outer_gate_kernel(const int* __restrict__ cu, const float* __restrict__ w1, const float* __restrict__ z1,
+                           const uint16_t* addend /* may alias out */, const uint16_t* __restrict__ hbag, uint16_t* out,
+                           float gate /* 0: no gating */, float* __restrict__ part_colsum /* nullable [parts][E] */,
+                           int n_q, BagPlan plan) {
+    using G = TileGeom<E_>;
+    constexpr int HR = 16;                                   // rows per step: one MFMA row block (half a 32-row tile)
+    constexpr int IMG = HR * E_ * 4;
+    constexpr int CH_PER_ROW = E_ / 8;                       // 16-byte chunks (8 bf16) per row
+    constexpr int NCH = HR * CH_PER_ROW / 64;
+    static_assert(CH_PER_ROW <= 64 && 64 % CH_PER_ROW == 0, "copy-out: a lane keeps one 8-column chunk");
+    __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeom sg = split_geom<4>(cu, plan, wave);
+    const int b = sg.b;
+    char* img = lds + wave * IMG;
+    const int c16 = lane & 15, g = lane >> 4;
+    const float* z1b = z1 + (size_t)b * n_q * E_;
+    bf16x8 zh[G::DT], zl[G::DT];
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) {
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qq = 4 * g + j;
+            const int qc = qq < n_q ? qq : n_q - 1;
+            z[j] = z1b[qc * E_ + 16 * t + c16] * (qq < n_q ? 1.0f : 0.0f);
+            z[4 + j] = 0.f;
+        }
+        pack_hi_lo(z, zh[t], zl[t]);
+    }
+    const float* w1b = w1 + (size_t)n_q * sg.row_begin;
+    const size_t slide_off = (size_t)sg.row_begin * E_;
+    const f32x4* add4 = reinterpret_cast<const f32x4*>(addend + slide_off);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(hbag + slide_off);
+    f32x4* out4 = reinterpret_cast<f32x4*>(out + slide_off);
+    f32x4 csum0 = {0.f, 0.f, 0.f, 0.f}, csum1 = csum0;       // column sums of the chunk this lane copies out
+    const int n_steps = 2 * sg.n_my;
+    auto step_row = [&](int st) { return sg.r0 + kTileRows * (wave + (st >> 1) * 4) + HR * (st & 1); };
+    // map values one step ahead (clamped addresses; masked when used), ADD / H chunks of the current step at its start:
+    // they are consumed after the MFMAs, and four waves per CU keep 64 KB in flight meanwhile
+    f32x4 wn;
+    auto fetch_w = [&](int st) {
+        const int mrow = min(step_row(st) + c16, sg.m_rows - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wn[r] = w1b[(size_t)min(4 * g + r, n_q - 1) * sg.m_rows + mrow];
+    };
+    if (n_steps > 0) fetch_w(0);
+    for (int st = 0; st < n_steps; ++st) {
+        const int row0 = step_row(st);
+        const int nvalid = max(0, min(HR, sg.r1 - row0));
+        float w[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            w[r] = (c16 < nvalid && 4 * g + r < n_q) ? wn[r] : 0.f;
+            w[4 + r] = 0.f;
+        }
+        fetch_w(st + 1 < n_steps ? st + 1 : st);
+        f32x4 av[NCH], hv[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = i * 64 + lane;
+            const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
+            const int grow = min(row0 + r, sg.m_rows - 1);
+            av[i] = add4[(size_t)grow * CH_PER_ROW + cc];
+            hv[i] = h4[(size_t)grow * CH_PER_ROW + cc];
+        }
+        {
+            const int row = c16;
+            bf16x8 wh, wl;
+            pack_hi_lo(w, wh, wl);
+#pragma unroll
+            for (int t = 0; t < G::DT; ++t) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                o = mfma_bf16(zh[t], wh, o);
+                o = mfma_bf16(zh[t], wl, o);
+                o = mfma_bf16(zl[t], wh, o);
+                const int c = (4 * t + g) ^ ((row & 7) << 1);
+                *reinterpret_cast<f32x4*>(img + row * (E_ * 4) + (c << 4)) = o;      // lane holds [row][16t + 4g .. +3]
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ci = i * 64 + lane;
+            const int r = ci / CH_PER_ROW, cc = ci % CH_PER_ROW;
+            // columns 8cc .. 8cc+7 = fp32 chunks 2cc and 2cc+1 (the swizzle leaves bit 0 alone: the pair stays adjacent)
+            const char* rowp = img + r * (E_ * 4);
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(rowp + (((2 * cc) ^ ((r & 7) << 1)) << 4));
+            const f32x4 o1 = *reinterpret_cast<const f32x4*>(rowp + (((2 * cc + 1) ^ ((r & 7) << 1)) << 4));
+            const bf16x8 ab = __builtin_bit_cast(bf16x8, av[i]);
+            const bf16x8 hb = __builtin_bit_cast(bf16x8, hv[i]);
+            bf16x8 ob;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (j < 4 ? o0[j] : o1[j - 4]) + (float)ab[j];
+                if (gate != 0.f) v *= (float)hb[j] > 0.f ? gate : 0.f;
+                ob[j] = f2bf(v);
+            }
+            if (r < nvalid) {
+                out4[(size_t)(row0 + r) * CH_PER_ROW + cc] = __builtin_bit_cast(f32x4, ob);
+                csum0 += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};   // what the caller would sum
+                csum1 += f32x4{(float)ob[4], (float)ob[5], (float)ob[6], (float)ob[7]};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (part_colsum != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int o = CH_PER_ROW; o < 64; o <<= 1) {                      // lanes l, l + CH_PER_ROW, ... share a chunk
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                csum0[j] += __shfl_xor(csum0[j], o);
+                csum1[j] += __shfl_xor(csum1[j], o);
+            }
+        }
+        if (lane < CH_PER_ROW) {                                         // lane == column chunk
+            *reinterpret_cast<f32x4*>(img + lane * 32) = csum0;
+            *reinterpret_cast<f32x4*>(img + lane * 32 + 16) = csum1;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < E_; idx += 256) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += reinterpret_cast<const float*>(lds + w * IMG)[idx];
+            part_colsum[(size_t)sg.part * E_ + idx] = a;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ gated (tanh on the fly) variants for K2
 // tanh(x) = 1 - 2 / (2^(2x log2 e) + 1): two transcendentals, saturates cleanly, abs error ~1e-7.
 __device__ __forceinline__ float fast_tanh(float v) {
@@ -1022,6 +1163,18 @@ int mpo_launch_bag_outer(const int* cu, int n_slides, int embed, const float* w1
     } else {
         MPO_E_SWITCH(embed, (bag_outer_kernel<EV, false><<<grid, 256, 0, stream>>>(cu, w1, z1, w2, z2, dx, n_q, plan)))
     }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_bag_outer_gate(const int* cu, int n_slides, int embed, const float* w1, const float* z1, const void* addend,
+                              const void* hbag, void* out, float gate, float* part_colsum, int n_q, const BagPlan& plan,
+                              hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
+    MPO_E_SWITCH(embed, (bag_outer_gate_kernel<EV><<<grid, 256, 0, stream>>>(cu, w1, z1, static_cast<const uint16_t*>(addend),
+                                                                            static_cast<const uint16_t*>(hbag),
+                                                                            static_cast<uint16_t*>(out), gate, part_colsum, n_q, plan)))
     MPO_LAUNCH_CHECK();
     return 0;
 }

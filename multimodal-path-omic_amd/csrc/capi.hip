@@ -139,7 +139,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 6; }
+int mpo_abi_version(void) { return 7; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -352,7 +352,7 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                 const float* out_w, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
-                                float* d_query, void* d_kbag, int dk_dtype, float* d_kbag_colsum, void* d_hbag,
+                                float* d_query, void* d_kbag, int dk_dtype, float* d_kbag_colsum, void* d_hbag, float* d_ctx,
                                 float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
                                 const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
@@ -364,7 +364,9 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     if (int rc = check_plan(splits, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
     float* dattn = ws.floats((size_t)R * E);
-    float* dctx = ws.floats((size_t)R * E);
+    float* dctx_ws = ws.floats((size_t)R * E);
+    float* dctx = d_ctx ? d_ctx : dctx_ws;                 // a caller that finishes dH itself keeps dL/dctx
+    MPO_CHECK(d_ctx != nullptr || d_hbag != nullptr, "nacagat backward: neither d_hbag nor d_ctx given");
     float* dqt = ws.floats((size_t)R * E);
     float* dtq = ws.floats((size_t)R * E);
     float* dq = ws.floats((size_t)R * E);
@@ -376,7 +378,7 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     MPO_CHECK(part_cs || !d_kbag_colsum, "nacagat backward: workspace too small (%zu bytes)", workspace_bytes);
     float* ds1_map = ws.floats((size_t)n_q * total_rows);
     float* dg_map = ws.floats((size_t)n_q * total_rows);
-    MPO_CHECK(dattn && dctx && dqt && dtq && dq && spare && dasum && part && part2 && ds1_map && dg_map,
+    MPO_CHECK(dattn && dctx_ws && dqt && dtq && dq && spare && dasum && part && part2 && ds1_map && dg_map,
               "nacagat backward: workspace too small (%zu bytes)", workspace_bytes);
     const float* qt = saved;
     const float* qs2 = qt + (size_t)R * E;
@@ -421,11 +423,33 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                          d_kbag, dk_dtype == MPO_F32, part_cs, n_q, splits, stream))) return rc;
     if (d_kbag_colsum)
         if ((rc = mpo_launch_colsum(part_cs, d_kbag_colsum, (int)plan_parts(splits), E, E, 0, stream))) return rc;
-    if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, attn_map, dctx, nullptr, nullptr, d_hbag, f32, n_q, splits, stream))) return rc;
+    if (d_ctx == nullptr)
+        if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, attn_map, dctx, nullptr, nullptr, d_hbag, f32, n_q, splits, stream))) return rc;
     // the key slice of the packed in-projection belongs to the caller's K = H W_k^T + b_k
     MPO_HIP(hipMemsetAsync(d_in_w + (size_t)E * E, 0, (size_t)E * E * sizeof(float), stream));
     if (d_kbag_colsum != d_in_b + E)            // (a caller may have the key-bias gradient written straight into its slice)
         MPO_HIP(hipMemsetAsync(d_in_b + E, 0, (size_t)E * sizeof(float), stream));
+    return 0;
+}
+
+int mpo_nacagat_patch_grad(const int32_t* cu_rows, int n_slides, int total_rows, int max_rows, int n_q, int embed,
+                           const float* attn_map, const float* d_ctx, const void* addend_bf16, const void* hbag_bf16,
+                           void* d_bag_bf16, float relu_gate, float* d_bias, const mpo_bag_plan* plan_,
+                           void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    if (int rc = check_common(MPO_BF16, n_slides, total_rows, max_rows, n_q, embed)) return rc;
+    MPO_CHECK(attn_map && d_ctx && addend_bf16 && hbag_bf16 && d_bag_bf16, "nacagat patch grad: null operand");
+    MPO_CHECK(((reinterpret_cast<uintptr_t>(addend_bf16) | reinterpret_cast<uintptr_t>(hbag_bf16) |
+                reinterpret_cast<uintptr_t>(d_bag_bf16)) & 15) == 0, "nacagat patch grad: bag operands must be 16-byte aligned");
+    const BagPlan splits = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(splits, n_slides)) return rc;
+    Arena ws(workspace, workspace_bytes);
+    float* part_cs = d_bias ? ws.floats(plan_parts(splits) * embed) : nullptr;
+    MPO_CHECK(part_cs || !d_bias, "nacagat patch grad: workspace too small (%zu bytes)", workspace_bytes);
+    int rc;
+    if ((rc = mpo_launch_bag_outer_gate(cu_rows, n_slides, embed, attn_map, d_ctx, addend_bf16, hbag_bf16, d_bag_bf16,
+                                        relu_gate, part_cs, n_q, splits, stream))) return rc;
+    if (d_bias)
+        if ((rc = mpo_launch_colsum(part_cs, d_bias, (int)plan_parts(splits), embed, embed, 0, stream))) return rc;
     return 0;
 }
 

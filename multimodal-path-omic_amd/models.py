@@ -198,8 +198,13 @@ class NarrowContextualAttentionGateTransformer(_FusionModelBase):
     def _make_co_attention(self, d):
         return PreGatingContextualAttention(embed_dim=d, num_heads=1)
 
+    _fused_bag_gate = True
+
     def _co_attend(self, g_bag, h_bags, inference):
-        return self.co_attention.forward_window(g_bag, h_bags)
+        gate = 0.0
+        if h_bags.data.dtype == torch.bfloat16:
+            gate = 1.0 / (1.0 - self.H[2].p) if self.training else 1.0
+        return self.co_attention.forward_window(g_bag, h_bags, bag_relu_gate=gate)
 
     def forward(self, wsi, omics):
         return self._forward_one(wsi, omics, True)

@@ -843,13 +843,16 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
     also for a bf16-stored bag: the gate multiplies k's rounding error (hard part 4)."""
 
     @staticmethod
-    def forward(ctx, query, bag_data, in_w, in_b, out_w, out_b, batch: BagBatch, drop_p: float):
+    def forward(ctx, query, bag_data, in_w, in_b, out_w, out_b, batch: BagBatch, drop_p: float, bag_relu_gate: float = 0.0):
         lib = L.lib()
         n_slides = batch.n_slides
         R, E = query.shape
         n_q = R // n_slides
         dev, T = query.device, batch.total_rows
         query = query.contiguous()
+        ctx.bag_relu_gate = float(bag_relu_gate)
+        if ctx.bag_relu_gate != 0.0 and bag_data.dtype != torch.bfloat16:
+            raise ValueError("bag_relu_gate (fused ReLU/dropout derivative of the patch layer) needs a bf16-stored bag")
         if bag_data.dtype == torch.bfloat16 and E == 256:
             # HIP key projection: bf16 bag (exact) x fp32 weights split into three bf16 terms, fp32 accumulate and output
             kbag = torch.empty(T, E, device=dev, dtype=torch.float32)
@@ -888,30 +891,43 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         d_map = d_map.contiguous() if d_map is not None else None
         d_query = torch.empty_like(query)
         d_k = torch.empty_like(kbag, dtype=bag_data.dtype)       # a bf16 bag takes its key gradient in bf16 (see below)
-        d_h = torch.empty_like(bag_data)
+        # bf16 bag: the patch-side gradient is finished by ONE pass after the dK W_k GEMM (mpo_nacagat_patch_grad) instead
+        # of outer-product kernel -> addmm_ read-modify-write -> element-wise derivative pass
+        fused_patch = bag_data.dtype == torch.bfloat16
+        d_h = None if fused_patch else torch.empty_like(bag_data)
+        d_ctx = torch.empty(R, E, device=dev, dtype=torch.float32) if fused_patch else None
         d_in_w, d_in_b, d_out_w, d_out_b = (grad_out(p) for p in ctx.param_refs)
         ws = _workspace(lib.mpo_nacagat_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows, T), dev)
         L.check(lib.mpo_coattn_nacagat_backward(
             L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
             _epoch(), L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
-            L.ptr(d_query), L.ptr(d_k), L.bag_dtype_code(d_k), L.ptr(d_in_b[E:2 * E]), L.ptr(d_h), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
+            L.ptr(d_query), L.ptr(d_k), L.bag_dtype_code(d_k), L.ptr(d_in_b[E:2 * E]), L.ptr(d_h), L.ptr(d_ctx), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
             L.ptr(d_out_b), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
         # back through the caller-side GEMM  K = H W_k^T + b_k.  The forward K stays fp32 (the gate amplifies its
         # rounding); its GRADIENT goes through bf16 operands with fp32 accumulation for a bf16 bag: dW_k as a
         # batched split-K product (one 480 000-deep fp32 contraction took 1.19 ms in rocBLAS), dH += dK W_k as a
         # bf16 GEMM (0.59 ms in fp32).
         w_k = in_w[E:2 * E]
-        if bag_data.dtype == torch.bfloat16:
-            d_h.addmm_(d_k, w_k.to(torch.bfloat16))       # in place: the out-of-place form first copies d_h (98 us for 245 MB)
+        if fused_patch:
+            d_h = torch.mm(d_k, w_k.to(torch.bfloat16))
+            gate = ctx.bag_relu_gate
+            colsum = torch.empty(E, device=dev, dtype=torch.float32) if gate != 0.0 else None
+            L.check(lib.mpo_nacagat_patch_grad(L.ptr(batch.cu), batch.n_slides, T, batch.max_rows, n_q, E, L.ptr(amap), L.ptr(d_ctx),
+                                               L.ptr(d_h), L.ptr(bag_data), L.ptr(d_h), gate, L.ptr(colsum), batch.plan(),
+                                               L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_nacagat_patch_grad")
+            if colsum is not None:
+                d_h._mpo_colsum = colsum          # the producing layer's bias gradient (PatchFcFn.backward picks it up)
             _splitk_tn(d_k, bag_data, d_in_w[E:2 * E])
         else:
             d_h.addmm_(d_k, w_k)
             torch.mm(d_k.t(), bag_data, out=d_in_w[E:2 * E])
         # (d_in_b[E:2E], the key bias gradient = column sums of d_k, came out of the kernel that wrote d_k)
-        return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None
+        return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None
 
 
-def coattn_nacagat(query, batch: BagBatch, in_w, in_b, out_w, out_b, drop_p: float):
-    """query (n_slides*n_q, E) -> (q_proj, attn_out (n_slides*n_q, E), ragged post-dropout map)."""
-    return CoAttnNaCAGaTFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, drop_p)
+def coattn_nacagat(query, batch: BagBatch, in_w, in_b, out_w, out_b, drop_p: float, bag_relu_gate: float = 0.0):
+    """query (n_slides*n_q, E) -> (q_proj, attn_out (n_slides*n_q, E), ragged post-dropout map).
+    bag_relu_gate = 1/(1-p) when the bag comes from patch_fc(..., pre_gated_grad=True): d_bag then already carries
+    that layer's ReLU/dropout derivative (bf16 bags only)."""
+    return CoAttnNaCAGaTFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, drop_p, bag_relu_gate)

@@ -145,3 +145,44 @@ def test_key_projection_matches_fp32_linear(dev, rows):
     assert torch.isnan(out[rows]).all()
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("lengths", [[1], [33, 5], [777, 64, 1500], [15000, 31, 4097]])
+@pytest.mark.parametrize("gate", [0.0, 1.0 / 0.75])
+def test_patch_grad_one_pass(dev, lengths, gate):
+    """mpo_nacagat_patch_grad against its definition on the same stored values:
+    d_bag = (A_drop^T d_ctx + addend) * (H > 0 ? gate : 0), column sums = the producing layer's bias gradient.
+    The outer product is accumulated in fp32 and the sum rounded to bf16 once: half a bf16 ulp of the result."""
+    from multimodal_path_omic_amd import _lib as L
+    from multimodal_path_omic_amd.ops import BagBatch
+    n_q, E = 6, C.E
+    g = torch.Generator().manual_seed(sum(lengths) + int(gate * 10))
+    T = sum(lengths)
+    h = torch.relu(torch.randn(T, E, generator=g)).to(torch.bfloat16)
+    addend = torch.randn(T, E, generator=g).to(torch.bfloat16)
+    maps = [torch.rand(n_q, m, generator=g) for m in lengths]                  # ragged [n_q][M_b] per slide
+    d_ctx = torch.randn(len(lengths) * n_q, E, generator=g)
+    ref = torch.cat([maps[b].double().t() @ d_ctx[b * n_q:(b + 1) * n_q].double() for b in range(len(lengths))])
+    ref = ref + addend.double()
+    if gate != 0.0:
+        ref = ref * (h.double() > 0) * gate
+    hd = h.to(dev)
+    batch = BagBatch.from_lengths(hd, lengths)
+    amap = torch.cat([m.reshape(-1) for m in maps]).to(dev)
+    out = torch.full((T + 1, E), float("nan"), device=dev, dtype=torch.bfloat16)   # guard row past the end
+    out[:T] = addend.to(dev)                                                    # in place: d_bag aliases addend
+    colsum = torch.empty(E, device=dev)
+    dc = d_ctx.to(dev)                         # (a temporary here would be freed -- and reused by plan() -- before the launch)
+    lib = L.lib()
+    ws = torch.empty(lib.mpo_nacagat_workspace_bytes(len(lengths), n_q, E, max(lengths), T), device=dev, dtype=torch.uint8)
+    L.check(lib.mpo_nacagat_patch_grad(L.ptr(batch.cu), len(lengths), T, max(lengths), n_q, E, L.ptr(amap), L.ptr(dc),
+                                       L.ptr(out), L.ptr(hd), L.ptr(out), gate, L.ptr(colsum), batch.plan(), L.ptr(ws), ws.numel(),
+                                       torch.cuda.current_stream().cuda_stream), "mpo_nacagat_patch_grad")
+    assert torch.isnan(out[T].float()).all()
+    got = out[:T].double().cpu()
+    # bf16 rounding of the result (half an ulp) + the outer product's own precision (hi/lo operand split without the
+    # lo x lo term: 2^-16 of its terms, which can move a sum across a rounding boundary)
+    tol = 2.0 ** -8 * ref.abs() + 1e-4
+    assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
+    cs_ref = got.sum(0)                                                         # sums of what was written
+    assert float((colsum.double().cpu() - cs_ref).abs().max()) <= 1e-4 * max(1.0, float(cs_ref.abs().max()))
