@@ -230,7 +230,9 @@ class CoAttnMCATFn(torch.autograd.Function):
     def forward(ctx, query, bag_data, in_w, in_b, out_w, out_b, batch: BagBatch, need_weights: bool,
                 bag_relu_gate: float = 0.0):
         lib = L.lib()
+        ctx.set_materialize_grads(False)
         ctx.bag_relu_gate = float(bag_relu_gate)
+        ctx.bag_bias = getattr(bag_data, "_mpo_bias_param", None)
         n_slides = batch.n_slides
         R, E = query.shape
         n_q = R // n_slides
@@ -258,14 +260,14 @@ class CoAttnMCATFn(torch.autograd.Function):
         batch, n_q = ctx.batch, ctx.n_q
         R, E = query.shape
         dev = query.device
-        d_out = d_out.contiguous()
+        d_out = d_out.contiguous() if d_out is not None else torch.zeros(R, E, device=dev)
         if d_map is not None:
             d_map = d_map.contiguous()
         d_query = torch.empty_like(query)
         d_bag = torch.empty_like(bag_data)
         # with the fused gate d_bag IS the patch layer's pre-activation gradient: its column sums (that layer's bias
         # gradient) fall out of the kernel's copy-out loop and travel on the tensor to PatchFcFn.backward
-        colsum = torch.empty(E, device=dev, dtype=torch.float32) if ctx.bag_relu_gate != 0.0 else None
+        colsum = _bias_grad_slot(ctx.bag_bias, E, dev) if ctx.bag_relu_gate != 0.0 else None
         d_in_w, d_in_b, d_out_w, d_out_b = (grad_out(p) for p in ctx.param_refs)
         ws = _workspace(lib.mpo_coattn_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows), dev)
         L.check(lib.mpo_coattn_mcat_backward(
@@ -287,6 +289,17 @@ def coattn_mcat(query, batch: BagBatch, in_w, in_b, out_w, out_b, need_weights: 
 
 
 stats = {"colsum_handoffs": 0}           # counters the tests read to make sure a fused path really ran
+
+
+def _bias_grad_slot(bag_param, E, dev):
+    """Where a co-attention backward writes the column sums of its (pre-gated) d_bag = the bias gradient of the patch
+    layer that produced the bag: straight into that bias's slice of the flat gradient bucket when patch_fc() tagged the
+    bag with its bias and the slice is still unset (PatchFcFn.backward then finds the data in place and skips its copy),
+    else a fresh tensor that travels on d_bag."""
+    if bag_param is not None and getattr(bag_param, "_mpo_grad_view", None) is not None and bag_param.grad is None \
+            and bag_param.numel() == E:
+        return bag_param._mpo_grad_view.view(E)
+    return torch.empty(E, device=dev, dtype=torch.float32)
 
 # Data-parallel steps split the backward in two: everything except the patch layer's weight gradient (dW_H = g^T X, a
 # 0.3 ms library GEMM that nothing downstream waits for) runs first, then the all-reduce of all other gradients is
@@ -343,7 +356,8 @@ class PatchFcFn(torch.autograd.Function):
         else:
             ready = getattr(dh, "_mpo_colsum", None)
             if ready is not None and ready.shape == db.shape:
-                db.copy_(ready)             # produced by the co-attention backward kernel while it wrote dh
+                if ready.data_ptr() != db.data_ptr():       # (already in the bucket slice when patch_fc tagged the bag)
+                    db.copy_(ready)         # produced by the co-attention backward kernel while it wrote dh
                 stats["colsum_handoffs"] += 1
             else:
                 _colsum_two_stage(g, db)
@@ -392,7 +406,10 @@ def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk
 
 
 def patch_fc(x_bf16, weight, bias, drop_p: float, pre_gated_grad: bool = False):
-    return PatchFcFn.apply(x_bf16, weight, bias, drop_p, pre_gated_grad)
+    h = PatchFcFn.apply(x_bf16, weight, bias, drop_p, pre_gated_grad)
+    if pre_gated_grad:
+        h._mpo_bias_param = bias          # lets the consumer's backward write this layer's bias gradient in place
+    return h
 
 
 # ------------------------------------------------------------------------------------ tail (6 x d tokens per slide)
@@ -551,6 +568,7 @@ class GatedPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, geom, head_p, rho_p, *params):
         lib = L.lib()
+        ctx.set_materialize_grads(False)
         branches, n_slides, Lr, d = geom
         bt = branches * n_slides
         x = x.contiguous()
@@ -706,6 +724,7 @@ class SurvivalHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits):
         lib = L.lib()
+        ctx.set_materialize_grads(False)
         logits = logits.contiguous()
         b, c = logits.shape
         hz, sv, y = (torch.empty_like(logits) for _ in range(3))
@@ -737,6 +756,7 @@ class CesLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hazards, survs, label, censorship, alpha, eps):
         lib = L.lib()
+        ctx.set_materialize_grads(False)        # an unused output must not cost a zero-fill launch in backward
         hazards, survs = hazards.contiguous(), survs.contiguous()
         label = label.view(-1).to(torch.int64).contiguous()
         censorship = censorship.view(-1).to(torch.float32).contiguous()
@@ -753,6 +773,8 @@ class CesLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss, _d_risk):
         lib = L.lib()
+        if d_loss is None:
+            return None, None, None, None, None, None
         hazards, survs, label, censorship = ctx.saved_tensors
         alpha, eps = ctx.cfg
         b, c = hazards.shape
@@ -777,6 +799,7 @@ class FusionHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hcat, *params):
         lib = L.lib()
+        ctx.set_materialize_grads(False)
         hcat = hcat.contiguous()
         b, din = hcat.shape
         hidden, dout, c = params[0].shape[0], params[2].shape[0], params[4].shape[0]
@@ -850,7 +873,9 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         n_q = R // n_slides
         dev, T = query.device, batch.total_rows
         query = query.contiguous()
+        ctx.set_materialize_grads(False)
         ctx.bag_relu_gate = float(bag_relu_gate)
+        ctx.bag_bias = getattr(bag_data, "_mpo_bias_param", None)
         if ctx.bag_relu_gate != 0.0 and bag_data.dtype != torch.bfloat16:
             raise ValueError("bag_relu_gate (fused ReLU/dropout derivative of the patch layer) needs a bf16-stored bag")
         if bag_data.dtype == torch.bfloat16 and E == 256:
@@ -912,7 +937,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         if fused_patch:
             d_h = torch.mm(d_k, w_k.to(torch.bfloat16))
             gate = ctx.bag_relu_gate
-            colsum = torch.empty(E, device=dev, dtype=torch.float32) if gate != 0.0 else None
+            colsum = _bias_grad_slot(ctx.bag_bias, E, dev) if gate != 0.0 else None
             L.check(lib.mpo_nacagat_patch_grad(L.ptr(batch.cu), batch.n_slides, T, batch.max_rows, n_q, E, L.ptr(amap), L.ptr(d_ctx),
                                                L.ptr(d_h), L.ptr(bag_data), L.ptr(d_h), gate, L.ptr(colsum), batch.plan(),
                                                L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_nacagat_patch_grad")
