@@ -135,6 +135,24 @@ __device__ __forceinline__ void gemm_f32_direct_body(const GemmArgs& g, DirectLd
     const bool gated = g.gate_mode != MPO_GATE_NONE;
     const bool want_bsum = g.bias_grad != nullptr && blockIdx.x == 0;
 
+    // epilogue operands of the output element this thread will own (thread t <-> element t of the tile): requested
+    // FIRST, so that their latency hides behind the fragment loads instead of adding a dependent round trip (bias, then
+    // mask, residual, old C) after the exchange -- these launches are latency chains, not throughput problems
+    const int erow = tid >> 4, ecol = tid & 15;
+    const int em = m0 + erow, en = n0 + ecol;
+    const bool e_in = em < g.M && en < g.N;
+    const size_t eo = (size_t)em * g.ldc + en;
+    const float e_bias = (e_in && g.bias) ? g.bias[en] : 0.f;
+    const float e_mask = (e_in && g.mask) ? g.mask[eo] : 1.0f;
+    const float e_res = (e_in && g.residual) ? g.residual[eo] : 0.f;
+    const float e_old = (e_in && g.accumulate) ? g.C[eo] : 0.f;
+    // ... and the element's dropout draw (Philox, ~50 instructions) while those loads are in flight
+    float e_keep = 1.0f;                                        // plain dropout: keep / (1 - p) or 0;  alpha dropout: 1 or 0
+    if (g.drop_p > 0.f) {
+        const unsigned long long doff = epoch_offset(g.drop_off, g.rng_epoch);
+        e_keep = dropout_keep(g.drop_seed, doff, eo, g.drop_p, g.alpha_dropout ? 1.0f : 1.0f / (1.0f - g.drop_p));
+    }
+
     const int kw = ((g.K + 63) >> 6) << 4;                      // k per wave, a multiple of 16
     const int kbeg = wave * kw, kend = min(g.K, kbeg + kw);
     const int nkb = kend > kbeg ? (kend - kbeg + 15) >> 4 : 0;
@@ -155,26 +173,16 @@ __device__ __forceinline__ void gemm_f32_direct_body(const GemmArgs& g, DirectLd
         if (lane < 16) lds.bsum[wave][lane] = bsum;
     }
     __syncthreads();
-    const int row = tid >> 4, col = tid & 15;
-    const int m = m0 + row, n = n0 + col;
-    if (m < g.M && n < g.N) {
+    if (e_in) {
         float v = (lds.part[0][tid] + lds.part[1][tid]) + (lds.part[2][tid] + lds.part[3][tid]);
-        v = (v + (g.bias ? g.bias[n] : 0.f)) * g.alpha;
+        v = (v + e_bias) * g.alpha;
         v = apply_act(v, g.act);
-        const size_t o = (size_t)m * g.ldc + n;
         if (g.drop_p > 0.f) {
-            const unsigned long long doff = epoch_offset(g.drop_off, g.rng_epoch);
-            if (g.alpha_dropout) {
-                const bool keep = dropout_keep(g.drop_seed, doff, o, g.drop_p, 1.0f) != 0.f;
-                v = alpha_drop_a(g.drop_p) * (keep ? v : kAlphaPrime) + alpha_drop_b(g.drop_p);
-            } else {
-                v *= dropout_keep(g.drop_seed, doff, o, g.drop_p, 1.0f / (1.0f - g.drop_p));
-            }
+            if (g.alpha_dropout) v = alpha_drop_a(g.drop_p) * (e_keep != 0.f ? v : kAlphaPrime) + alpha_drop_b(g.drop_p);
+            else v *= e_keep;
         }
-        if (g.mask) v *= g.mask[o];
-        if (g.residual) v += g.residual[o];
-        if (g.accumulate) v += g.C[o];
-        g.C[o] = v;
+        v = v * e_mask + e_res + e_old;
+        g.C[eo] = v;
     }
     if (want_bsum && tid < DB && m0 + tid < g.M)
         g.bias_grad[m0 + tid] = (lds.bsum[0][tid] + lds.bsum[1][tid]) + (lds.bsum[2][tid] + lds.bsum[3][tid]);
