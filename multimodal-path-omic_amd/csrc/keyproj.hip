@@ -26,7 +26,7 @@ namespace {
 //  global -> wait -> scratch -> LDS, which serialised the whole pipeline)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Diagnostic builds only (tests/gpu_probe_keyproj_variants.py): bit 0 drops the stores, bit 1 the LDS reads + MFMAs,
+// Diagnostic builds only (tools/gpu_probe_keyproj_variants.py): bit 0 drops the stores, bit 1 the LDS reads + MFMAs,
 // bit 2 the global loads.  The product is built with 0.
 #ifndef KP_VARIANT
 #define KP_VARIANT 0

@@ -387,7 +387,7 @@ def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk
     """g^T x with the (huge) row dimension split into batches: (S, d, C) @ (S, C, k) -> sum_S, fp32.
     The batch count is chosen so that the library's 256 x 256 output tiles fill the 256 CUs exactly once
     (480 000 x 256 x 1024: 64 batches of 7 500 rows = 284 us; 117 batches of 4 102 = 344 us; 29 of 16 551 = 663 us,
-    tests/gpu_time_splitk.py); target_chunk > 0 forces a chunk length instead."""
+    tools/gpu_time_splitk.py); target_chunk > 0 forces a chunk length instead."""
     rows = g.shape[0]
     if target_chunk > 0:
         s = max(1, rows // target_chunk)

@@ -63,7 +63,7 @@ def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kin
         # later slides sit behind Adam steps, which amplify last-bit gradient differences (g / sqrt(v)).  NaCAGaT's
         # trajectory is ill-conditioned in the reference algorithm itself: the CPU oracle's own validation risks move
         # by 5e-3 (epoch 0) / 1.4e-2 (epoch 1) under a 1e-5 relative perturbation of the patch features, MCAT's by
-        # 1.5e-6 (tests/cpu_cohort_sensitivity.py) -- hence the two bars.
+        # 1.5e-6 (tools/cpu_cohort_sensitivity.py) -- hence the two bars.
         traj_tol = 2e-2 if kind == "nacagat" else 5e-3
         assert np.abs(risks - ref_r).max() < traj_tol, np.abs(risks - ref_r).max()
         assert np.abs(losses - ref_l).max() < traj_tol

@@ -184,7 +184,7 @@ def test_big_mcat_matches_oracle(dev, dtype):
         err = float((prm.grad.cpu() - ref).abs().max()) / scale
         # H.*: d(pre-activation) passes through ReLU's kink -- of the 614 400 pre-activations a few lie within the 6e-6
         # forward difference between the GPU and CPU fp32 GEMMs and flip their mask; one flipped element moves a row of
-        # dW_H by |dH| |x| ~ 3e-5, i.e. 6e-3 of this fixture's tiny gradient scale (tests/gpu_diag_big4.py: the gradient
+        # dW_H by |dH| |x| ~ 3e-5, i.e. 6e-3 of this fixture's tiny gradient scale (tools/gpu_diag_big4.py: the gradient
         # ARRIVING at H_bag agrees to 4e-6)
         tol = (1e-2 if n.startswith("H.") else 2e-3) if dtype == torch.float32 else (2e-2 if n.startswith("H.") else 1e-2)
         assert err < tol, (n, err)
@@ -265,7 +265,7 @@ def test_other_omic_group_counts_and_tiny_bags(dev, kind, n_groups):
         # bar 1e-2: with up to 16 tokens x 512 FFN units x 2 layers x 2 encoders x 6 slides (~2e5 ReLU pre-activations) one
         # that lies within rounding of zero can flip its mask against the CPU oracle and move a row of that layer's
         # weight gradient (seen once: nacagat, 16 groups, 7.9e-3 at path_transformer.layers.0.linear1.weight, while the
-        # co-attention module alone agrees to 1.5e-5 at 16 queries, tests/gpu_diag_nq16.py); everything else is < 1e-3
+        # co-attention module alone agrees to 1.5e-5 at 16 queries, tools/gpu_diag_nq16.py); everything else is < 1e-3
         assert err < 1e-2, (n, err)
     print(f"worst gradient error [{kind}, {n_groups} groups]: {worst[0]:.2e} at {worst[1]}")
 
