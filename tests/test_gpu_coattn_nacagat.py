@@ -149,14 +149,15 @@ def test_key_projection_matches_fp32_linear(dev, rows):
 
 @pytest.mark.parametrize("lengths", [[1], [33, 5], [777, 64, 1500], [15000, 31, 4097]])
 @pytest.mark.parametrize("gate", [0.0, 1.0 / 0.75])
-def test_patch_grad_one_pass(dev, lengths, gate):
+@pytest.mark.parametrize("E", [128, 256])
+def test_patch_grad_one_pass(dev, lengths, gate, E):
     """mpo_nacagat_patch_grad against its definition on the same stored values:
     d_bag = (A_drop^T d_ctx + addend) * (H > 0 ? gate : 0), column sums = the producing layer's bias gradient.
     The outer product is accumulated in fp32 and the sum rounded to bf16 once: half a bf16 ulp of the result."""
     from multimodal_path_omic_amd import _lib as L
     from multimodal_path_omic_amd.ops import BagBatch
-    n_q, E = 6, C.E
-    g = torch.Generator().manual_seed(sum(lengths) + int(gate * 10))
+    n_q = 6
+    g = torch.Generator().manual_seed(sum(lengths) + int(gate * 10) + E)
     T = sum(lengths)
     h = torch.relu(torch.randn(T, E, generator=g)).to(torch.bfloat16)
     addend = torch.randn(T, E, generator=g).to(torch.bfloat16)
