@@ -23,7 +23,9 @@ template <int E_, bool F32BAG>
 struct FwdCfg {
     static constexpr int NT = F32BAG ? 2 : 1;                       // image tiles per wave (hi [+ lo])
     static constexpr int WAVES = (F32BAG && E_ == 512) ? 2 : 4;     // LDS budget 160 KiB
-    static constexpr int WAVE_LDS = NT * TileGeom<E_>::TILEB;
+    // bf16 bag, E <= 256: tiles travel global -> LDS directly (global_load_lds_dwordx4), two images per wave
+    static constexpr bool DMA = !F32BAG && E_ <= 256;
+    static constexpr int WAVE_LDS = (DMA ? 2 : NT) * TileGeom<E_>::TILEB;
     static constexpr int ML_OFF = WAVES * WAVE_LDS;                 // [WAVES][16][2] floats after the images
     static constexpr int LDS_BYTES = ML_OFF + WAVES * 128;
 };
@@ -113,7 +115,58 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
 
     const int tstride = kTileRows * WAVES;
     const int t0row = r0 + kTileRows * wave;
-    if constexpr (!F32BAG) {
+    if constexpr (C::DMA) {
+        // The tile goes global -> LDS without passing through registers: no staging registers, no ds_write, and the
+        // wait for a tile is counted BY HAND (hipcc does not track these loads; with register staging it waited for both
+        // tiles in flight before staging one, so the stream ran in bursts: 4.8 TB/s where this schedule -- one tile
+        // ahead, tools/gpu_probe_readbw.py -- reads 6.1).  A wave-instruction fills 1 KiB of the image linearly
+        // (lane l -> byte 16 l), so the image's chunk swizzle is applied to the GLOBAL chunk each lane fetches.
+        constexpr int CH = E_ / 8;                                // 16-byte chunks per bag row
+        constexpr int RPI = 64 / CH;                              // rows per wave-instruction
+        constexpr int NI = kTileRows / RPI;                       // wave-instructions per tile
+        static_assert(64 % CH == 0 && NI * 1024 == G::TILEB, "one wave-instruction = 1 KiB of whole rows");
+        auto issue = [&](int trow, char* image) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int r = RPI * k + lane / CH, cs = lane % CH;
+                const int c = cs ^ ((r & 7) << 1);
+                const int grow = min(trow + r, m_rows - 1);       // rows past the slide: clamped (finite; masked in the tile)
+                // (inline asm, not __builtin_amdgcn_global_load_lds: hipcc tracks the builtin's LDS write and puts a
+                //  vmcnt(0) in front of the tile's transposing LDS reads, i.e. waits for the NEXT tile in mid-tile.
+                //  Untracked loads only make its own waits for other memory operations stricter, never weaker.)
+                const char* src = slide + ((size_t)grow * CH + c) * 16;
+                const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(image + k * 1024);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"                   // m0 is "reserved": nothing else in this kernel uses it
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                             :: "v"(src), "s"(dst) : "memory", "m0");
+#pragma clang diagnostic pop
+            }
+        };
+        // s_waitcnt vmcnt(N): N = loads that may still be outstanding (the tile just requested)
+        constexpr int kWaitNext = (NI & 15) | ((NI >> 4) << 14) | 0x0F70;
+        constexpr int kWaitAll = 0x0F70;
+        char* img1 = thi + G::TILEB;
+        if (n_my > 0) issue(t0row, thi);
+        for (int it = 0; it < n_my; ++it) {
+            const int trow = t0row + it * tstride;
+            char* cur = (it & 1) ? img1 : thi;
+            if (it + 1 < n_my) {
+                issue(trow + tstride, (it & 1) ? thi : img1);     // its last readers finished with the previous tile
+                __builtin_amdgcn_s_waitcnt(kWaitNext);
+            } else {
+                __builtin_amdgcn_s_waitcnt(kWaitAll);
+            }
+            asm volatile("" ::: "memory");                        // the tile's LDS reads stay below the wait
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            fwd_tile<E_, 1>(cur, cur, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
+                            s_row ? s_row + trow : nullptr, q_live, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // (the merge below reuses image 0 of every wave)
+    } else if constexpr (!F32BAG) {
         // bf16 bag: TWO tiles in flight per wave (32 KiB), register sets alternate (static names: unrolled by 2)
         Stage<E_, false> sa, sb;
         if (n_my > 0) sa.load(slide, t0row, m_rows, 0, lane);

@@ -43,6 +43,45 @@ __global__ __launch_bounds__(256) void rd_blocked(const f32x4* __restrict__ p, s
     for (int u = 1; u < U; ++u) s += acc[u];
     if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = 1.f;
 }
+// each wave streams its own 16 KB tiles straight into LDS (no VGPR staging), then sums them from LDS
+__global__ __launch_bounds__(256) void rd_lds(const char* __restrict__ p, size_t nbytes, float* out, float* out_sums) {
+    __shared__ __attribute__((aligned(16))) char lds[4][2][16384];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t per_wg = nbytes / gridDim.x;
+    const char* base = p + per_wg * blockIdx.x;
+    const int ntiles = (int)(per_wg / 16384);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int t, int buf) {
+        const char* src = base + (size_t)t * 16384;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(&lds[wave][buf][k * 1024]), 16, 0, 0);
+    };
+    int t = wave;
+    if (t < ntiles) issue(t, 0);
+    int buf = 0;
+    for (; t < ntiles; t += 4) {
+        if (t + 4 < ntiles) issue(t + 4, buf ^ 1);
+        if (t + 4 < ntiles) __builtin_amdgcn_s_waitcnt(0x4F70); else __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += *reinterpret_cast<const f32x4*>(&lds[wave][buf][k * 1024 + lane * 16]);
+        buf ^= 1;
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = 1.f;
+    if (out_sums != nullptr) {                               // correctness check: per-wave sum of everything it streamed
+        float v = acc[0] + acc[1] + acc[2] + acc[3];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) out_sums[blockIdx.x * 4 + wave] = v;
+    }
+}
+
+extern "C" void launch_lds_check(const void* p, size_t nbytes, float* out, float* sums, int grid, hipStream_t st) {
+    rd_lds<<<grid, 256, 0, st>>>((const char*)p, nbytes, out, sums);
+}
+extern "C" void launch_lds(const void* p, size_t nbytes, float* out, int grid, hipStream_t st) {
+    rd_lds<<<grid, 256, 0, st>>>((const char*)p, nbytes, out, nullptr);
+}
 extern "C" void launch_blocked(int u, const void* p, size_t n16, float* out, int grid, hipStream_t st) {
     const f32x4* q = (const f32x4*)p;
     if (u == 4) rd_blocked<4><<<grid, 256, 0, st>>>(q, n16, out);
@@ -66,6 +105,7 @@ bufs = [torch.randn(nbytes // 4, device=dev) for _ in range(2)]
 out = torch.zeros(4, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 lib.launch_blocked.argtypes = lib.launch.argtypes
+lib.launch_lds.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 for blocked, u, wg_per_cu in [(0, 4, 1), (0, 4, 2), (0, 8, 1), (1, 4, 1), (1, 4, 2), (1, 8, 1), (1, 8, 2), (1, 8, 4)]:
     if True:
         grid = 256 * wg_per_cu
@@ -79,3 +119,30 @@ for blocked, u, wg_per_cu in [(0, 4, 1), (0, 4, 2), (0, 8, 1), (1, 4, 1), (1, 4,
         e.record(); torch.cuda.synchronize()
         us = a.elapsed_time(e) / 20 * 1e3
         print(f"{'per-WG contiguous regions' if blocked else 'one global sweep         '} U={u:2d} loads in flight/thread, {wg_per_cu:2d} WG/CU: {us:6.1f} us  {nbytes / us / 1e6:5.2f} TB/s", flush=True)
+
+# direct-to-LDS loads (global_load_lds_dwordx4): 4 waves per CU, 16 KB tiles, double-buffered per wave, waits counted by hand
+run = lambda i: lib.launch_lds(bufs[i & 1].data_ptr(), nbytes, out.data_ptr(), 256, st)
+for i in range(4): run(i)
+torch.cuda.synchronize()
+a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for i in range(20): run(i)
+e.record(); torch.cuda.synchronize()
+us = a.elapsed_time(e) / 20 * 1e3
+print(f"direct-to-LDS tiles, 1 WG/CU (4 waves, one tile ahead): {us:6.1f} us  {nbytes / us / 1e6:5.2f} TB/s", flush=True)
+
+# does every wave really see its tiles in LDS (images of waves 2, 3 lie above 64 KB)?
+lib.launch_lds_check.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+small = torch.randint(-8, 9, (nbytes // 4,), device=dev).float()          # integers: sums are exact in fp32
+sums = torch.zeros(256 * 4, device=dev)
+lib.launch_lds_check(small.data_ptr(), nbytes, out.data_ptr(), sums.data_ptr(), 256, st)
+torch.cuda.synchronize()
+per_wg = nbytes // 256
+ref = torch.zeros(256, 4, dtype=torch.float64)
+v = small.double().cpu().view(256, per_wg // 4)
+ntiles = per_wg // 16384
+for w in range(4):
+    idx = torch.arange(w, ntiles, 4)
+    ref[:, w] = v[:, : ntiles * 4096].view(256, ntiles, 4096)[:, idx].sum((1, 2))
+err = float((sums.double().cpu().view(256, 4) - ref).abs().max())
+print("direct-to-LDS correctness: max |sum error| over 1024 waves =", err, flush=True)
