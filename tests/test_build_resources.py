@@ -52,3 +52,28 @@ def test_headline_kernels_are_register_resident(usage):
         assert match, f"kernel {h} not found in the build"
         for v in match:
             assert v["scratch_bytes"] == 0 and v["vgpr_spill"] == 0, (h, v)
+
+
+def test_m0_is_only_touched_by_the_direct_to_lds_loads(tmp_path):
+    """K1 forward issues its tile loads from inline asm that sets M0 (the LDS destination of global_load_lds_dwordx4)
+    and lists it as clobbered, which the compiler only honours as long as it has no use of M0 of its own in that kernel.
+    Compile the file to assembly and check that every M0 access sits inside one of those asm blocks."""
+    import os
+    import subprocess
+    src = os.path.join(_build.CSRC, "coattn_fwd.hip")
+    out = tmp_path / "coattn_fwd.s"
+    flags = [f for f in _build.FLAGS if not f.startswith("-Rpass")]
+    subprocess.run(["hipcc", *flags, "-S", "--cuda-device-only", src, "-o", str(out)], check=True, capture_output=True)
+    in_asm, inside, outside = False, 0, []
+    for line in out.read_text().splitlines():
+        if "ASMSTART" in line:
+            in_asm = True
+        elif "ASMEND" in line:
+            in_asm = False
+        elif "m0" in line.split(";")[0].replace(",", " ").split():
+            if in_asm:
+                inside += 1
+            else:
+                outside.append(line.strip())
+    assert inside > 0, "the direct-to-LDS loads are gone: drop this test together with them"
+    assert not outside, f"the compiler uses M0 outside the asm blocks: {outside[:3]}"
