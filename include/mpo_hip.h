@@ -49,10 +49,7 @@ enum { MPO_ACT_NONE_ = 0, MPO_ACT_RELU_ = 1, MPO_ACT_ELU_ = 2, MPO_ACT_TANH_ = 3
 
 int mpo_abi_version(void);
 const char* mpo_last_error(void);
-/* Once per process and device, outside any stream capture: creates the library's one helper stream and its
- * events.  Backward entries fork their weight-gradient work onto it and join before returning (two parallel
- * branches under HIP-graph capture).  enable_side_stream = 0 keeps everything on the caller's stream. */
-int mpo_prepare_device(int enable_side_stream);
+/* Every entry launches on the caller's stream only: the library owns no stream and no event. */
 
 /* ---- building block: y = act(alpha * (x W^T + b)) and its two backward products, on the fp32 MFMA.
  * Stands in for torch.nn.functional.linear on the 6 x 256-token tail. */
@@ -190,10 +187,7 @@ int mpo_nacagat_patch_grad(const int32_t* cu_rows, int n_slides, int total_rows,
  * (seed, offset): pass the same pair to forward and backward, reserve *_rng_span() counters per call.
  * rng_epoch (nullable, device uint64): added x 2^40 to every stream offset inside the kernels, so a HIP graph
  * that froze (seed, offset) at capture still draws fresh masks on every replay once the host bumps *rng_epoch
- * as part of the graph.  Eager callers pass NULL.
- * Backward entries of K4/K5/K6 take `phase`: 3 = everything; 1 = only the critical data chain (input gradients;
- * intermediates stay in the workspace); 2 = only the weight / LayerNorm-parameter gradients, to be called afterwards
- * with the SAME workspace, typically on another stream so that it overlaps the HBM-bound kernels upstream. ==== */
+ * as part of the graph.  Eager callers pass NULL. ==== */
 
 /* ---- K4: set-Transformer = nn.TransformerEncoder(post-norm layers, nhead, dim_feedforward, relu), no final
  * norm.  Replaces models/mcat/mcat.py:51-53,60-62 (call :101-102); torch/nn/modules/transformer.py:661.
@@ -211,7 +205,7 @@ int mpo_encoder_forward(const float* x, int n_branches, int n_slides, int T, int
                         float* y, float* saved, mpo_stream_t stream);
 int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, int d, int ff, int heads, int layers,
                          const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
-                         const float* saved, const float* dy, float* dx, float* const* grads, int phase,
+                         const float* saved, const float* dy, float* dx, float* const* grads,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ---- K5: gated attention-MIL pooling = AttentionNetGated (models/blocks.py:13-48) + softmax pooling + rho
@@ -228,7 +222,7 @@ int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, 
 int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                             float head_drop_p, float rho_drop_p, const float* saved, const float* h,
                             const float* dh, const float* d_scores_ext /* nullable */, float* dx, float* const* grads,
-                            int phase, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+                            void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ---- K6: ConcatFusion (models/fusion.py:7-19) + classifier + survival head (models/mcat/mcat.py:119-138).
  * hcat [n_slides, din] = [h_path | h_omic] -> hazards, survs, Y [n_slides, n_classes].
@@ -241,7 +235,7 @@ int mpo_fusion_head_forward(const float* hcat, int n_slides, int din, int hidden
 int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
                              const float* const* params, const float* saved, const float* hazards,
                              const float* survs, const float* y, const float* d_hazards, const float* d_survs,
-                             const float* d_y, float* d_hcat, float* const* grads, int phase,
+                             const float* d_y, float* d_hcat, float* const* grads,
                              void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ---- survival head alone (for fusion layers other than `concat`, whose MLP K6 has built in): hazards = sigmoid(logits),

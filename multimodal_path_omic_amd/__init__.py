@@ -1,13 +1,8 @@
-"""Importable alias of the package directory `multimodal-path-omic_amd/`.
+"""MI355X-native WSI-patch x omics fusion path (MCAT / NaCAGaT hot path).
 
-A hyphen cannot appear in a Python module name, so `import multimodal_path_omic_amd`
-resolves here and this stub re-points the package at the real directory: sub-module
-imports (`multimodal_path_omic_amd.blocks`, ...) are served from there.
+Host side is Python on PyTorch-ROCm; every kernel is hand-written HIP for gfx950
+behind the C-ABI declared in include/mpo_hip.h (libmpo_hip.so, loaded by `_lib`).
+Importing the package is cheap and GPU-free; the first call of any op loads the
+library and raises if it is missing -- there is no CPU or eager fallback.
 """
-import os as _os
-
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
-                      "multimodal-path-omic_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+__version__ = "0.1.0"

@@ -46,7 +46,6 @@ _SIGNATURES = {
                                         _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
-    "mpo_prepare_device": (c_int, [c_int]),
     "mpo_colsum_bf16": (c_int, [_P, _P, ctypes.c_int64, c_int, _P]),
     "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     "mpo_patch_epilogue_forward": (c_int, [_P, _P, ctypes.c_int64, c_int, c_float, c_uint64, c_uint64, _P, _P]),
@@ -68,16 +67,16 @@ _SIGNATURES = {
     "mpo_encoder_workspace_bytes": (c_size_t, [c_int] * 4),
     "mpo_encoder_rng_span": (c_uint64, [c_int] * 5),
     "mpo_encoder_forward": (c_int, [_P] + [c_int] * 7 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P]),
-    "mpo_encoder_backward": (c_int, [_P] + [c_int] * 7 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "mpo_encoder_backward": (c_int, [_P] + [c_int] * 7 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_gated_pool_saved_floats": (c_size_t, [c_int] * 3),
     "mpo_gated_pool_workspace_bytes": (c_size_t, [c_int] * 3),
     "mpo_gated_pool_rng_span": (c_uint64, [c_int] * 3),
     "mpo_gated_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_float, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P]),
-    "mpo_gated_pool_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "mpo_gated_pool_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_fusion_head_saved_floats": (c_size_t, [c_int] * 4),
     "mpo_fusion_head_workspace_bytes": (c_size_t, [c_int] * 4),
     "mpo_fusion_head_forward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P, _P, _P]),
-    "mpo_fusion_head_backward": (c_int, [_P] + [c_int] * 5 + [_P] * 10 + [c_int, _P, c_size_t, _P]),
+    "mpo_fusion_head_backward": (c_int, [_P] + [c_int] * 5 + [_P] * 10 + [_P, c_size_t, _P]),
     "mpo_omic_snn_saved_floats": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_workspace_bytes": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_rng_span": (c_uint64, [c_int] * 3),
@@ -112,22 +111,6 @@ def lib():
     return _lib
 
 
-_prepared = set()
-
-
-def prepare_device(device):
-    """Create the library's helper stream for `device` (must happen outside graph capture; ops call this on
-    every entry, it is a set lookup after the first time)."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _prepared:
-        with torch.cuda.device(idx):
-            # The library side stream (weight gradients beside the dX chain) is OPT-IN: measured r01, forking onto a
-            # library-created stream inside torch's stream capture segfaults hipStreamEndCapture on ROCm 7.2
-            # (eager mode is fine), so the default keeps every launch on the caller's stream.
-            check(lib().mpo_prepare_device(1 if os.environ.get("MPO_SIDE_STREAM") else 0), "mpo_prepare_device")
-        _prepared.add(idx)
-
-
 def check(rc: int, what: str):
     if rc != 0:
         msg = lib().mpo_last_error()
@@ -154,7 +137,6 @@ def ptr_array(tensors):
 
 
 def stream_of(t):
-    prepare_device(t.device)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

@@ -35,71 +35,11 @@ struct Arena {
 };
 static inline size_t arena_need(size_t acc, size_t n_floats) { return align_up(acc, 256) + n_floats * 4; }
 
-// ---------------------------------------------------------------------------- side stream (per device)
-namespace {
-constexpr int kEvRing = 256;
-struct DeviceSide {
-    hipStream_t side = nullptr;
-    hipEvent_t ev[kEvRing] = {};
-    int next = 0;
-    bool ready = false;
-    hipEvent_t take() { hipEvent_t e = ev[next]; next = (next + 1) % kEvRing; return e; }
-};
-DeviceSide g_side[16];
-bool g_side_enabled = true;
-}  // namespace
-
-SideFork::SideFork(hipStream_t main_stream) : main(main_stream), side(nullptr), active(false) {
-    int dev = 0;
-    if (!g_side_enabled || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_side[dev].ready) return;
-    side = g_side[dev].side;
-    active = true;
-}
-hipStream_t SideFork::sync() {
-    if (!active) return main;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    hipEvent_t e = g_side[dev].take();
-    if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        active = false;                                // degrade to the caller's stream (still correct: in order)
-        return main;
-    }
-    return side;
-}
-int SideFork::join() {
-    if (side == nullptr) return 0;
-    int dev = 0;
-    MPO_HIP(hipGetDevice(&dev));
-    hipEvent_t e = g_side[dev].take();
-    MPO_HIP(hipEventRecord(e, side));
-    MPO_HIP(hipStreamWaitEvent(main, e, 0));
-    return 0;
-}
-
-extern "C" int mpo_prepare_device(int enable_side_stream) {
-    g_side_enabled = enable_side_stream != 0;
-    int dev = 0;
-    MPO_HIP(hipGetDevice(&dev));
-    MPO_CHECK(dev >= 0 && dev < 16, "device index %d out of range", dev);
-    DeviceSide& d = g_side[dev];
-    if (d.ready) return 0;
-    MPO_HIP(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
-    for (int i = 0; i < kEvRing; ++i) MPO_HIP(hipEventCreateWithFlags(&d.ev[i], hipEventDisableTiming));
-    d.ready = true;
-    return 0;
-}
-
 // ONE workgroup per CU over the window (256 CUs): long row ranges amortise the per-workgroup prologue
 // (query fragments) and epilogue (LDS merge, partial write); measured r01 on 32 x 15k bf16:
 // 256 WGs 51.6 us, 512 59.0, 1024 73.0, 2048 98.9.
 extern "C" int mpo_coattn_target_workgroups(void) {
-    static const int target = [] {
-        const char* e = getenv("MPO_COATTN_TARGET_WGS");
-        int t = e ? atoi(e) : 256;
-        return t < 1 ? 1 : (t > 1024 ? 1024 : t);
-    }();
-    return target;
+    return 256;
 }
 
 extern "C" int mpo_coattn_splits(int n_slides, int max_rows) {

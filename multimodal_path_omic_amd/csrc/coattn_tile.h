@@ -10,12 +10,12 @@
 //     -> the MFMA 16x16x32 operand "row p, k = 32s + 8g .. +7";
 //   * transposed reads ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns
 //     and receives them column-major -> the operand "row = column d, k = patch".
-// The image is filled through registers (global_load_dwordx4 issued a tile ahead, written
-// with ds_write after the previous tile's MFMA work: the T14 issue-early / write-late split
-// of cdna_hip_programming.md).  A bf16 bag is copied as is; an fp32 bag is split into a bf16
-// hi tile and a bf16 lo tile (x = hi + lo keeps ~16 mantissa bits through the bf16 MFMAs).
-// (LDS-DMA was tried first: hipcc drains it with vmcnt(0) before the transposed reads, which
-// serialises the prefetch; register staging lets the compiler count vmcnt itself.)
+// How the image is filled depends on the kernel: the forward pass of a bf16 bag (E <= 256) sends its tiles
+// global -> LDS directly (global_load_lds_dwordx4 from inline asm with hand-counted waits, coattn_fwd.hip: the
+// chunk swizzle is applied to the GLOBAL chunk a lane fetches, the LDS side stays linear); every other pass
+// stages through registers with the Stage struct below (global_load_dwordx4 issued a tile ahead, ds_write after
+// the previous tile's MFMA work: the T14 issue-early / write-late split of cdna_hip_programming.md).  A bf16
+// bag is copied as is; an fp32 bag is split into a bf16 hi tile and a bf16 lo tile.
 //
 // Orientation of every MFMA: the query index is always the MFMA column (lane & 15),
 // so a lane's running max / sum / rescale factor belong to the same query as all of

@@ -1,0 +1,114 @@
+// Small-row fp32 GEMM on the fp32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, k-ordered fma chain).
+//
+// Everything after the co-attention runs on N x d = 6 x 256 tokens per slide:
+// the q/k-fold/v-unfold/out projections of K1/K2, the four linears of the Contextual Attention Gate,
+// the set-Transformer projections and FFN, the gated-MIL branches, rho, fusion and classifier, and all
+// of their backward products.  With a window of slides batched the row count is 6 x n_slides.
+//
+//   C[m][n] = epilogue( alpha * ( sum_k A(m,k) * B(n,k) + bias[n] ) )
+//   A(m,k) = A_KC ? A[m*lda + k] : A[k*lda + m]       B(n,k) = B_KC ? B[n*ldb + k] : B[k*ldb + n]
+// which covers  y = x W^T + b   (A_KC, B_KC),  dx = dy W  (A_KC, !B_KC)  and  dW = dy^T x  (!A_KC, !B_KC).
+// Epilogue: activation, optional keep-mask multiply (dropout), optional residual add, optional
+// accumulate into C (beta = 1).
+//
+// The kernels live in gemm_f32_direct.h (16 x 16 outputs per workgroup, the four waves split K, fragments
+// straight from L2); this file holds the launchers and the bias-gradient column sum.
+#include "mpo_common.h"
+#include "mpo_kernels.h"
+#include "gemm_f32_gate.h"
+
+namespace {
+
+constexpr int DB = 16;
+constexpr int DMAXB = 8;
+}  // namespace
+void mpo_direct_single_nb4(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream);
+void mpo_direct_single_nb8(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream);
+void mpo_direct_group_nb4(const GemmGroup& grp, dim3 grid, hipStream_t stream);
+void mpo_direct_group_nb8(const GemmGroup& grp, dim3 grid, hipStream_t stream);
+namespace {
+inline int direct_nbmax(int k) { return k <= 256 ? 4 : DMAXB; }
+void launch_direct_single(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream) {
+    if (direct_nbmax(g.K) == 4) mpo_direct_single_nb4(g, layout, grid, stream);
+    else mpo_direct_single_nb8(g, layout, grid, stream);
+}
+void launch_direct_group(const GemmGroup& grp, dim3 grid, hipStream_t stream) {
+    int kmax = 0;
+    for (int i = 0; i < grp.n; ++i) kmax = grp.g[i].K > kmax ? grp.g[i].K : kmax;
+    // a launch that fills the chip several times over is throughput-bound: the 4-block variant's smaller register
+    // footprint (4 instead of 2 workgroups per CU) then beats having all of K in flight at once
+    const size_t wgs = (size_t)grid.x * grid.y * grid.z;
+    if (wgs > 1024 || direct_nbmax(kmax) == 4) mpo_direct_group_nb4(grp, grid, stream);
+    else mpo_direct_group_nb8(grp, grid, stream);
+}
+
+// colsum[n] (+)= sum_m X[m][n]   (bias gradients, merging per-workgroup partials): 16 columns per workgroup, 16 row
+// groups of 16 lanes (64 columns x 4 row groups left a [1024][256] merge on 4 workgroups: 62 us)
+__global__ __launch_bounds__(256)
+void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N, int ld, int accumulate) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
+    float s = 0.f;
+    if (n < N)
+        for (int m = rg; m < M; m += 16) s += x[(size_t)m * ld + n];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][c];
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+
+}  // namespace
+
+int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0) return 0;
+    MPO_CHECK(g.K > 0, "gemm: K must be positive (got %d)", g.K);
+    dim3 dgrid((g.N + DB - 1) / DB, (g.M + DB - 1) / DB);
+    launch_direct_single(g, 2 * (a_kc ? 1 : 0) + (b_kc ? 1 : 0), dgrid, stream);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_gemm_group(const GemmGroup& grp, int a_kc, int b_kc, hipStream_t stream) {
+    MPO_CHECK(grp.n >= 1 && grp.n <= 8, "grouped gemm: 1..8 members (got %d)", grp.n);
+    int mx = 0, nx = 0;
+    for (int i = 0; i < grp.n; ++i) {
+        MPO_CHECK(grp.g[i].K > 0, "grouped gemm: member %d has K = %d", i, grp.g[i].K);
+        if (grp.g[i].M > mx) mx = grp.g[i].M;
+        if (grp.g[i].N > nx) nx = grp.g[i].N;
+    }
+    if (mx <= 0 || nx <= 0) return 0;
+    GemmGroup tagged = grp;
+    for (int i = 0; i < tagged.n; ++i) tagged.g[i].layout = 2 * (a_kc ? 1 : 0) + (b_kc ? 1 : 0);
+    dim3 dgrid((nx + DB - 1) / DB, (mx + DB - 1) / DB, grp.n);
+    launch_direct_group(tagged, dgrid, stream);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_gemm_mixed(const GemmGroup& grp, hipStream_t stream) {
+    MPO_CHECK(grp.n >= 1 && grp.n <= 8, "mixed grouped gemm: 1..8 members (got %d)", grp.n);
+    int mx = 0, nx = 0;
+    for (int i = 0; i < grp.n; ++i) {
+        MPO_CHECK(grp.g[i].K > 0, "mixed grouped gemm: member %d has K = %d", i, grp.g[i].K);
+        MPO_CHECK(grp.g[i].layout >= 0 && grp.g[i].layout <= 3, "mixed grouped gemm: member %d has layout %d", i, grp.g[i].layout);
+        if (grp.g[i].M > mx) mx = grp.g[i].M;
+        if (grp.g[i].N > nx) nx = grp.g[i].N;
+    }
+    if (mx <= 0 || nx <= 0) return 0;
+    dim3 dgrid((nx + DB - 1) / DB, (mx + DB - 1) / DB, grp.n);
+    launch_direct_group(grp, dgrid, stream);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_colsum(const float* x, float* out, int M, int N, int ld, int accumulate, hipStream_t stream) {
+    if (N <= 0) return 0;
+    colsum_kernel<<<(N + 15) / 16, 256, 0, stream>>>(x, out, M, N, ld, accumulate);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}

@@ -233,19 +233,6 @@ int mpo_launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n,
                          float wd, int step, const int* step_dev, hipStream_t stream);
 int mpo_launch_colsum_bf16(const void* x, float* out, size_t rows, int cols, hipStream_t stream);
 
-// ---- library-owned side stream: work that is off the critical path of a family's backward (weight-gradient
-// GEMMs, LayerNorm parameter reductions) is issued on it: sync() makes the side stream wait for everything the
-// caller's stream has been given so far (the producers of the side work's inputs), join() makes the caller's
-// stream wait for the side work.  Under stream capture this becomes parallel branches of the graph.
-// The stream and its event ring are created by mpo_prepare_device(); without it everything stays on `main`.
-struct SideFork {
-    hipStream_t main, side;
-    bool active;
-    explicit SideFork(hipStream_t main_stream);
-    hipStream_t sync();                              // returns the stream to launch the side work on
-    int join();
-};
-
 // gated (tanh on the fly) single-pass variants for K2 (bagops.hip)
 int mpo_launch_bag_rowdot_gated(const void* bag, int bag_f32, const int* cu, int n_slides, int embed, const float* r1,
                                 const float* r2, float* a_map, float* g_map, int n_q, const BagPlan& plan, hipStream_t stream);

@@ -56,24 +56,8 @@ inline GateSpec gate_rng(DropSpec d) {
 }
 
 #define RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
-// Backward entries take `phase`: 1 = the critical data chain only (input gradients; intermediates stay in the
-// workspace), 2 = the weight / LayerNorm-parameter gradients only (reads those intermediates; run it later, e.g. on
-// another stream, with the SAME workspace), 3 = both in one call.
-#define MAIN(expr) do { if (phase & 1) RC(expr); } while (0)
-#define SIDE(expr) do { if (phase & 2) RC(expr); } while (0)
-// a layer's dx (layout 2) and dW (layout 0) products: one mixed launch when both phases run in this call
-#define PAIR(dxa, dwa) do { \
-        if (phase == 3) RC(mpo_linear_bwd_pair((dxa), (dwa), stream)); \
-        else { if (phase & 1) RC(mpo_launch_gemm((dxa), 1, 0, stream)); if (phase & 2) RC(mpo_launch_gemm((dwa), 0, 0, side.get())); } \
-    } while (0)
-struct SideSel {                        // stream for the weight-gradient launches of this call
-    SideFork fork;
-    hipStream_t main;
-    int phase;
-    SideSel(hipStream_t s, int ph) : fork(s), main(s), phase(ph) {}
-    hipStream_t get() { return phase == 3 ? fork.sync() : main; }
-    int join() { return phase == 3 ? fork.join() : 0; }
-};
+// a layer's dx (layout 2) and dW (layout 0) products share one mixed launch
+#define PAIR(dxa, dwa) RC(mpo_linear_bwd_pair((dxa), (dwa), stream))
 
 // ------------------------------------------------------------------------------------------- K4 encoder
 enum { P_INW, P_INB, P_OUTW, P_OUTB, P_L1W, P_L1B, P_L2W, P_L2B, P_N1W, P_N1B, P_N2W, P_N2B, P_PER_LAYER };
@@ -193,20 +177,17 @@ int mpo_encoder_forward(const float* x, int n_branches, int n_slides, int T, int
 
 int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, int d, int ff, int heads, int layers,
                          const float* const* params, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
-                         const float* saved, const float* dy, float* dx, float* const* grads, int phase,
+                         const float* saved, const float* dy, float* dx, float* const* grads,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     MPO_CHECK(n_branches >= 1 && n_branches <= kMaxBranches, "encoder: 1..%d branches (got %d)", kMaxBranches, n_branches);
     const int NB = n_branches, R = n_slides * T, RT = NB * R, BT = NB * n_slides;
     const uint64_t stride = enc_stream_stride(BT, T, d, ff);
     MPO_CHECK(layers <= 8, "encoder: at most 8 layers (got %d)", layers);
-    MPO_CHECK(phase >= 1 && phase <= 3, "backward phase must be 1, 2 or 3 (got %d)", phase);
     EncLayerSaved S[8];
     Carver c(const_cast<float*>(saved));
     for (int l = 0; l < layers; ++l) enc_carve(c, &S[l], BT, T, d, ff, heads);
     Arena ws(workspace, workspace_bytes);
-    // phase 3: each layer's dx and dW products share one grouped launch.  Phases 1 / 2 split the critical data chain from
-    // the weight / LayerNorm-parameter gradients (nothing is updated in place, every layer has its own buffer set).
-    SideSel side(stream, phase);
+    // each layer's dx and dW products share one grouped launch (every layer has its own buffer set)
     const float* dcur = dy;
     const size_t Rd = (size_t)R * d, Rf = (size_t)R * ff, Rq = (size_t)R * 3 * d;
     for (int l = layers - 1; l >= 0; --l) {
@@ -231,17 +212,16 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
         }
         // one grouped launch per product pair: members (dx_br, dW_br) for every branch
         auto pairs = [&](auto&& mk_dx, auto&& mk_dw) -> int {
-            GroupBuilder main_g, side_g;
+            GroupBuilder main_g;
             for (int br = 0; br < NB; ++br) {
-                if (phase & 1) RC(main_g.add(mk_dx(br)));
-                if (phase & 2) RC((phase == 3 ? main_g : side_g).add(mk_dw(br)));
+                RC(main_g.add(mk_dx(br)));
+                RC(main_g.add(mk_dw(br)));
             }
             RC(main_g.launch(stream));
-            if (side_g.g.n) RC(side_g.launch(side.get()));
             return 0;
         };
         // x2 = LN2(s2)
-        RC(mpo_launch_ln_bwd_br(dcur, S[l].s2, S[l].st2, n2, ds2, RT, d, 0, phase, phase == 2 ? side.get() : stream));
+        RC(mpo_launch_ln_bwd_br(dcur, S[l].s2, S[l].st2, n2, ds2, RT, d, 0, 3, stream));
         // s2 = x1 + drop3(f W2^T + b2)
         RC(pairs([&](int br) { return mpo_args_bwd_input(ds2 + br * Rd, P(br, P_L2W), df + br * Rf, R, ff, d, 1.0f, 0, gate_rng_br(d3, br, Rd)); },
                  [&](int br) { return mpo_args_bwd_weight(ds2 + br * Rd, S[l].f + br * Rf, G(br, P_L2W), G(br, P_L2B), R, ff, d, 1.0f, gate_rng_br(d3, br, Rd)); }));
@@ -256,11 +236,11 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
                  [&](int br) { return mpo_args_bwd_weight(df + br * Rf, S[l].x1 + br * Rd, G(br, P_L1W), G(br, P_L1B), R, d, ff, 1.0f,
                                                           gate(S[l].f + br * Rf, MPO_GATE_RELU, drop_p)); }));
         // x1 = LN1(s1)
-        RC(mpo_launch_ln_bwd_br(dx1, S[l].s1, S[l].st1, n1, ds1, RT, d, 0, phase, phase == 2 ? side.get() : stream));
+        RC(mpo_launch_ln_bwd_br(dx1, S[l].s1, S[l].st1, n1, ds1, RT, d, 0, 3, stream));
         // s1 = in + drop1(o W_o^T + b_o)
         RC(pairs([&](int br) { return mpo_args_bwd_input(ds1 + br * Rd, P(br, P_OUTW), dob + br * Rd, R, d, d, 1.0f, 0, gate_rng_br(d1, br, Rd)); },
                  [&](int br) { return mpo_args_bwd_weight(ds1 + br * Rd, S[l].o + br * Rd, G(br, P_OUTW), G(br, P_OUTB), R, d, d, 1.0f, gate_rng_br(d1, br, Rd)); }));
-        MAIN(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, BT, T, d, heads, stream));
+        RC(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, BT, T, d, heads, stream));
         // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in
         RC(pairs([&](int br) {
                      GemmArgs g;
@@ -271,7 +251,6 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
                  [&](int br) { return mpo_args_bwd_weight(dqkv + br * Rq, in + br * Rd, G(br, P_INW), G(br, P_INB), R, d, 3 * d, 1.0f); }));
         dcur = din;
     }
-    RC(side.join());
     return 0;
 }
 
@@ -325,9 +304,8 @@ int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, 
 
 int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                             float head_drop_p, float rho_drop_p, const float* saved, const float* h,
-                            const float* dh, const float* d_scores_ext, float* dx, float* const* grads, int phase,
+                            const float* dh, const float* d_scores_ext, float* dx, float* const* grads,
                             void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
-    MPO_CHECK(phase >= 1 && phase <= 3, "backward phase must be 1, 2 or 3 (got %d)", phase);
     MPO_CHECK(n_branches >= 1 && n_branches <= 2, "gated pool backward: 1..2 branches (got %d)", n_branches);
     const int NB = n_branches, R = n_slides * L, RT = NB * R, BT = NB * n_slides;
     const size_t Rd = (size_t)R * d, Bd = (size_t)n_slides * d;
@@ -343,45 +321,36 @@ int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L,
     MPO_CHECK(dhpool && dscores && dab && da && db, "gated pool backward: workspace too small (%zu bytes)", workspace_bytes);
     auto P = [&](int br, int i) { return params[br * 8 + i]; };
     auto G = [&](int br, int i) { return grads[br * 8 + i]; };
-    SideSel side(stream, phase);                            // weight gradients beside the dx chain (no buffer is rewritten)
     auto pairs = [&](auto&& mk_dx, auto&& mk_dw) -> int {
-        GroupBuilder main_g, side_g;
+        GroupBuilder main_g;
         for (int br = 0; br < NB; ++br) {
-            if (phase & 1) RC(main_g.add(mk_dx(br)));
-            if (phase & 2) RC((phase == 3 ? main_g : side_g).add(mk_dw(br)));
+            RC(main_g.add(mk_dx(br)));
+            RC(main_g.add(mk_dw(br)));
         }
         RC(main_g.launch(stream));
-        if (side_g.g.n) RC(side_g.launch(side.get()));
         return 0;
     };
     // h = drop(relu(hpool W_rho^T + b_rho))
     RC(pairs([&](int br) { return mpo_args_bwd_input(dh + br * Bd, P(br, 6), dhpool + br * Bd, n_slides, d, d, 1.0f, 0, gate(h + br * Bd, MPO_GATE_RELU, rho_drop_p)); },
              [&](int br) { return mpo_args_bwd_weight(dh + br * Bd, hpool + br * Bd, G(br, 6), G(br, 7), n_slides, d, d, 1.0f, gate(h + br * Bd, MPO_GATE_RELU, rho_drop_p)); }));
-    MAIN(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, BT, L, d, stream));
+    RC(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, BT, L, d, stream));
     // scores = ab W_c^T + b_c
     RC(pairs([&](int br) { return mpo_args_bwd_input(dscores + (size_t)br * R, P(br, 4), dab + br * Rd, R, d, 1, 1.0f, 0); },
              [&](int br) { return mpo_args_bwd_weight(dscores + (size_t)br * R, ab + br * Rd, G(br, 4), G(br, 5), R, d, 1, 1.0f); }));
-    MAIN(mpo_launch_ew_mul2(dab, b, a, da, db, RT * d, stream));                 // da = dab * b,  db = dab * a
+    RC(mpo_launch_ew_mul2(dab, b, a, da, db, RT * d, stream));                 // da = dab * b,  db = dab * a
     // a = drop(tanh(x W_a^T + b_a)), b = drop(sigmoid(x W_b^T + b_b)): dx accumulates both products, the second follows alone
     {
-        GroupBuilder first, second, side_g;
+        GroupBuilder first, second;
         for (int br = 0; br < NB; ++br) {
             const GateSpec ga = gate(a + br * Rd, MPO_GATE_TANH, head_drop_p), gb = gate(b + br * Rd, MPO_GATE_SIGMOID, head_drop_p);
-            if (phase & 1) {
-                RC(first.add(mpo_args_bwd_input(da + br * Rd, P(br, 0), dx + br * Rd, R, d, d, 1.0f, 1, ga)));
-                RC(second.add(mpo_args_bwd_input(db + br * Rd, P(br, 2), dx + br * Rd, R, d, d, 1.0f, 1, gb)));
-            }
-            if (phase & 2) {
-                GroupBuilder& wg = phase == 3 ? first : side_g;
-                RC(wg.add(mpo_args_bwd_weight(da + br * Rd, x + br * Rd, G(br, 0), G(br, 1), R, d, d, 1.0f, ga)));
-                RC(wg.add(mpo_args_bwd_weight(db + br * Rd, x + br * Rd, G(br, 2), G(br, 3), R, d, d, 1.0f, gb)));
-            }
+            RC(first.add(mpo_args_bwd_input(da + br * Rd, P(br, 0), dx + br * Rd, R, d, d, 1.0f, 1, ga)));
+            RC(second.add(mpo_args_bwd_input(db + br * Rd, P(br, 2), dx + br * Rd, R, d, d, 1.0f, 1, gb)));
+            RC(first.add(mpo_args_bwd_weight(da + br * Rd, x + br * Rd, G(br, 0), G(br, 1), R, d, d, 1.0f, ga)));
+            RC(first.add(mpo_args_bwd_weight(db + br * Rd, x + br * Rd, G(br, 2), G(br, 3), R, d, d, 1.0f, gb)));
         }
         RC(first.launch(stream));
         RC(second.launch(stream));
-        if (side_g.g.n) RC(side_g.launch(side.get()));
     }
-    RC(side.join());
     return 0;
 }
 
@@ -417,9 +386,8 @@ int mpo_fusion_head_forward(const float* hcat, int n_slides, int din, int hidden
 int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
                              const float* const* P, const float* saved, const float* hazards, const float* survs,
                              const float* y, const float* d_hazards, const float* d_survs, const float* d_y,
-                             float* d_hcat, float* const* G, int phase, void* workspace, size_t workspace_bytes,
+                             float* d_hcat, float* const* G, void* workspace, size_t workspace_bytes,
                              mpo_stream_t stream) {
-    MPO_CHECK(phase >= 1 && phase <= 3, "backward phase must be 1, 2 or 3 (got %d)", phase);
     Carver c(const_cast<float*>(saved));
     const float* z1 = c.take((size_t)n_slides * hidden); const float* z2 = c.take((size_t)n_slides * dout);
     Arena ws(workspace, workspace_bytes);
@@ -427,15 +395,13 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
     float* dz2 = ws.floats((size_t)n_slides * dout);
     float* dz1 = ws.floats((size_t)n_slides * hidden);
     MPO_CHECK(dlogits && dz2 && dz1, "fusion head backward: workspace too small (%zu bytes)", workspace_bytes);
-    SideSel side(stream, phase);
-    MAIN(mpo_launch_head_bwd(hazards, survs, y, d_hazards, d_survs, d_y, dlogits, n_slides, n_classes, stream));
+    RC(mpo_launch_head_bwd(hazards, survs, y, d_hazards, d_survs, d_y, dlogits, n_slides, n_classes, stream));
     PAIR(mpo_args_bwd_input(dlogits, P[4], dz2, n_slides, dout, n_classes, 1.0f, 0),
          mpo_args_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f));
     PAIR(mpo_args_bwd_input(dz2, P[2], dz1, n_slides, hidden, dout, 1.0f, 0, gate(z2, MPO_GATE_RELU)),
          mpo_args_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, gate(z2, MPO_GATE_RELU)));
     PAIR(mpo_args_bwd_input(dz1, P[0], d_hcat, n_slides, din, hidden, 1.0f, 0, gate(z1, MPO_GATE_RELU)),
          mpo_args_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, gate(z1, MPO_GATE_RELU)));
-    RC(side.join());
     return 0;
 }
 

@@ -35,19 +35,11 @@ class FlatGradBucket:
             off += p.numel()
 
     def begin(self):
-        import os
-        from . import ops
-        # Opt-in: measured r01 under graph replay, deferring the tail's weight-gradient GEMMs to a second stream is
-        # SLOWER (2.57 vs 2.34 ms per window): they contend with the HBM-bound kernels they were meant to hide under.
-        ops.defer_weight_grads = self.flat.is_cuda and bool(os.environ.get("MPO_DEFER"))
         for p in self.params:
             p.grad = None
+            p._mpo_slice_taken = False
 
     def finish(self):
-        from . import ops
-        if self.flat.is_cuda:
-            ops.join_deferred(self.flat.device)          # weight gradients written on the deferred stream
-        ops.defer_weight_grads = False
         for p in self.params:
             view = p._mpo_grad_view
             if p.grad is None:

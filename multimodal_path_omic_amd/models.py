@@ -12,7 +12,6 @@ format: accumulation stays fp32, the 6 x d tail stays fp32 -- SURVEY.md section 
 """
 from __future__ import annotations
 
-import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -80,55 +79,23 @@ class _FusionModelBase(nn.Module):
         """omics: per group a (B, d_i) tensor -> G_bag (B, N, d)."""
         return ops.omic_snn(omics, self.G, self.training)
 
-    def _omic_branch(self, g_bag):
-        omic = self.omic_transformer(g_bag)
-        return ops.gated_pool(omic, self.omic_attention_head, self.omic_rho, self.training)
-
-    def _path_branch(self, h_coattn):
-        path = self.path_transformer(h_coattn)
-        return ops.gated_pool(path, self.path_attention_head, self.path_rho, self.training)
-
     # ---- window API
     def forward_window(self, bags: BagBatch, omics: "List[torch.Tensor]", inference: bool = False):
         """bags: raw patch features (total_rows, 1024) of the window; omics: per group (B, d_i).
         Returns hazards, survs, Y (B, C) and {'coattn': [ (N, M_b) ] | None, 'path': (B,1,N), 'omic': (B,1,N)}.
 
-        The omic branch (T_G + rho_G, models/mcat/mcat.py:102,111-115) depends only on G_bag, so it is forked
-        onto a side HIP stream and runs next to the patch layer and the co-attention, which are HBM-bound and
-        leave the matrix/vector pipes idle; autograd replays its backward on the same stream.  Eagerly the
-        step is host-bound and this buys nothing; inside a captured graph (harness.GraphedWindowStep) the two
-        chains really overlap."""
+        The path and the omic set-Transformer / pooling head have identical geometry and run as ONE launch sequence
+        with grouped GEMMs (ops.encoder_stacked, ops.gated_pool_stacked): the token tail is a latency-bound chain of
+        small launches, so the omic branch rides along in launches the path branch needs anyway."""
         g_bag = self._omic_fc(omics)
-        if self.batch_branches:
-            # the path and the omic set-Transformer / pooling head have identical geometry: run them as ONE launch
-            # sequence with grouped GEMMs.  The token tail is a latency-bound chain of small launches, so the omic
-            # branch rides along for free (no second stream, nothing to overlap by luck).
-            h_bags = self._patch_fc(bags)
-            h_coattn, a_coattn = self._co_attend(g_bag, h_bags, inference)
-            tokens = ops.encoder_stacked(torch.stack([h_coattn, g_bag]),
-                                         [list(self.path_transformer.layers), list(self.omic_transformer.layers)], self.training)
-            a, h = ops.gated_pool_stacked(tokens, [self.path_attention_head, self.omic_attention_head],
-                                          [self.path_rho, self.omic_rho], self.training)
-            hazards, survs, y = self._fuse_and_head(h[0], h[1], h)
-            return hazards, survs, y, {"coattn": a_coattn, "path": a[0], "omic": a[1]}
-        fork = self.fork_omic_branch and g_bag.is_cuda
-        if fork:
-            main = torch.cuda.current_stream(g_bag.device)
-            side = self._side_stream(g_bag.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                a_omic, h_omic = self._omic_branch(g_bag)
         h_bags = self._patch_fc(bags)
         h_coattn, a_coattn = self._co_attend(g_bag, h_bags, inference)
-        a_path, h_path = self._path_branch(h_coattn)
-        if fork:
-            main.wait_stream(side)
-            for t in (a_omic, h_omic):
-                t.record_stream(main)
-        else:
-            a_omic, h_omic = self._omic_branch(g_bag)
-        hazards, survs, y = self._fuse_and_head(h_path, h_omic)
-        return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
+        tokens = ops.encoder_stacked(torch.stack([h_coattn, g_bag]),
+                                     [list(self.path_transformer.layers), list(self.omic_transformer.layers)], self.training)
+        a, h = ops.gated_pool_stacked(tokens, [self.path_attention_head, self.omic_attention_head],
+                                      [self.path_rho, self.omic_rho], self.training)
+        hazards, survs, y = self._fuse_and_head(h[0], h[1], h)
+        return hazards, survs, y, {"coattn": a_coattn, "path": a[0], "omic": a[1]}
 
     def _fuse_and_head(self, h_path, h_omic, stacked=None):
         """Fusion + classifier + survival head (models/mcat/mcat.py:119-138).  `concat` is one K6 call; the other fusion
@@ -140,16 +107,6 @@ class _FusionModelBase(nn.Module):
             return ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
         fused = self.fusion_layer(h_path, h_omic)
         return ops.survival_head(ops.linear(fused, self.classifier.weight, self.classifier.bias))
-
-    fork_omic_branch = not bool(os.environ.get("MPO_NO_FORK"))
-    batch_branches = not bool(os.environ.get("MPO_NO_BRANCH_BATCH"))     # A/B switch: fall back to two chains (+ fork)
-
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            object.__setattr__(self, "_side", st)
-        return st
 
     def _forward_one(self, wsi, omics, inference):
         """The reference's call: wsi (1,M,1024) or (M,1024); omics list of (1,d_i) or (d_i,)."""

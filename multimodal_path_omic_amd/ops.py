@@ -108,7 +108,11 @@ def grad_out(p):
     adopted by autograd as `p.grad` (no accumulate kernel); otherwise a fresh tensor is returned and
     autograd adds it."""
     view = getattr(p, "_mpo_grad_view", None)
-    if view is not None and p.grad is None:
+    if view is not None and p.grad is None and not getattr(p, "_mpo_slice_taken", False):
+        # the slice is handed out ONCE per window (FlatGradBucket.begin() clears the flag): the kernels overwrite their
+        # gradient outputs, so a second producer of the same parameter (two forwards before one backward, tied
+        # weights) gets its own tensor and autograd adds the two
+        p._mpo_slice_taken = True
         return view.view(p.shape)          # a FRESH alias: autograd only steals a gradient nobody else references
     return torch.empty_like(p)
 
@@ -125,51 +129,6 @@ def set_rng_epoch(t):
 
 def _epoch():
     return L.ptr(_rng_epoch_tensor) if _rng_epoch_tensor is not None else None
-
-
-# ---- deferred weight-gradient work (phase 2 of the tail backward entries)
-_defer_stream = {}
-# Only the window harness turns this on (FlatGradBucket.begin .. finish brackets it and joins the stream):
-# a plain caller reads gradients on its own stream right after backward() and must not race a second stream.
-defer_weight_grads = False
-
-
-def _grads_in_bucket(params, grads):
-    return all(getattr(p, "_mpo_grad_view", None) is not None and g.data_ptr() == p._mpo_grad_view.data_ptr()
-               for p, g in zip(params, grads))
-
-
-def _two_phase(call, ws, device, params=(), grads=()):
-    """Run a backward entry as phase 1 (data chain) on the current stream and phase 2 (weight gradients) on a
-    second stream that waits for phase 1: the weight-gradient GEMMs then overlap whatever the main stream does
-    next (upstream layers, the HBM-bound co-attention / patch-layer backward).  join_deferred() -- called by
-    FlatGradBucket.finish() -- makes the main stream wait for them before the gradients are used."""
-    if not defer_weight_grads or not _grads_in_bucket(params, grads):
-        call(3)             # (a fresh gradient tensor is accumulated by autograd on THIS stream: no deferral)
-        return
-    main = torch.cuda.current_stream(device)
-    side = _defer_stream.get(device)
-    if side is None:
-        side = _defer_stream[device] = torch.cuda.Stream(device=device)
-    call(1)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        call(2)
-    ws.record_stream(side)
-
-
-def _keep_for_side(t):
-    """Tensors read by deferred phase-2 work must not be recycled by the allocator before that work ran."""
-    if defer_weight_grads and t is not None and t.is_cuda:
-        side = _defer_stream.get(t.device)
-        if side is not None:
-            t.record_stream(side)
-
-
-def join_deferred(device):
-    side = _defer_stream.get(device)
-    if side is not None:
-        torch.cuda.current_stream(device).wait_stream(side)
 
 
 def _workspace(nbytes, device):
@@ -297,8 +256,8 @@ def _bias_grad_slot(bag_param, E, dev):
     bag with its bias and the slice is still unset (PatchFcFn.backward then finds the data in place and skips its copy),
     else a fresh tensor that travels on d_bag."""
     if bag_param is not None and getattr(bag_param, "_mpo_grad_view", None) is not None and bag_param.grad is None \
-            and bag_param.numel() == E:
-        return bag_param._mpo_grad_view.view(E)
+            and bag_param.numel() == E and not getattr(bag_param, "_mpo_slice_taken", False):
+        return bag_param._mpo_grad_view.view(E)         # (PatchFcFn.backward's grad_out(bias) then claims this slice)
     return torch.empty(E, device=dev, dtype=torch.float32)
 
 # Data-parallel steps split the backward in two: everything except the patch layer's weight gradient (dW_H = g^T X, a
@@ -398,7 +357,13 @@ def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk
             s //= 2
     c = rows // s
     main = s * c
-    part = torch.bmm(g[:main].view(s, c, -1).transpose(1, 2), x[:main].view(s, c, -1), out_dtype=torch.float32)
+    ga, xa = g[:main].view(s, c, -1).transpose(1, 2), x[:main].view(s, c, -1)
+    # r01 record (gpurun_out/fwdgemm.log, tools/README.md): a batched library GEMM given a stride-0 (expanded) operand
+    # faulted the GPU.  These are plain views of two dense matrices; refuse anything else before it reaches the library.
+    for t in (ga, xa):
+        if any(st == 0 and n > 1 for st, n in zip(t.stride(), t.shape)):
+            raise RuntimeError(f"split-K product: operand with a zero stride {tuple(t.stride())} for shape {tuple(t.shape)}")
+    part = torch.bmm(ga, xa, out_dtype=torch.float32)
     torch.sum(part, 0, out=out)
     if main < rows:
         out += torch.mm(g[main:].t(), x[main:], out_dtype=torch.float32)
@@ -435,10 +400,6 @@ def gated_scores(x, wa, ba, wb, bb, wc, bc, drop_p: float):
         a = F.dropout(a, drop_p, True)
         b = F.dropout(b, drop_p, True)
     return linear(a * b, wc, bc)
-
-
-class _ParamFn(torch.autograd.Function):
-    """Shared plumbing: parameters arrive as *args tensors and leave as one gradient per tensor."""
 
 
 class CagFn(torch.autograd.Function):
@@ -513,11 +474,9 @@ class EncoderFn(torch.autograd.Function):
         ws = _workspace(lib.mpo_encoder_workspace_bytes(branches * n_slides, T, d, ff), x.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         dy = dy.contiguous()
-        _two_phase(lambda ph: L.check(lib.mpo_encoder_backward(
+        L.check(lib.mpo_encoder_backward(
             L.ptr(x), branches, n_slides, T, d, ff, heads, layers, pa, drop_p, seed, off, _epoch(), L.ptr(saved), L.ptr(dy),
-            L.ptr(dx), ga, ph, L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_encoder_backward"), ws, x.device, ctx.param_refs, grads)
-        for t in (dy, saved, x):
-            _keep_for_side(t)
+            L.ptr(dx), ga, L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_encoder_backward")
         return (dx, None, None, *grads)
 
 
@@ -599,11 +558,9 @@ class GatedPoolFn(torch.autograd.Function):
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         dh = dh.contiguous()
         d_sc = d_scores.contiguous() if d_scores is not None else None
-        _two_phase(lambda ph: L.check(lib.mpo_gated_pool_backward(
-            L.ptr(x), branches, n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h), L.ptr(dh), L.ptr(d_sc), L.ptr(dx), ga, ph,
-            L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_gated_pool_backward"), ws, x.device, ctx.param_refs, grads)
-        for t in (dh, saved, x, h):
-            _keep_for_side(t)
+        L.check(lib.mpo_gated_pool_backward(
+            L.ptr(x), branches, n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h), L.ptr(dh), L.ptr(d_sc), L.ptr(dx), ga,
+            L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_gated_pool_backward")
         return (dx, None, None, None, *grads)
 
 
@@ -824,12 +781,9 @@ class FusionHeadFn(torch.autograd.Function):
         ws = _workspace(lib.mpo_fusion_head_workspace_bytes(b, hidden, dout, c), hcat.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         dhz, dsv, dy = (t.contiguous() if t is not None else None for t in (dhz, dsv, dy))
-        _two_phase(lambda ph: L.check(lib.mpo_fusion_head_backward(
+        L.check(lib.mpo_fusion_head_backward(
             L.ptr(hcat), b, din, hidden, dout, c, pa, L.ptr(saved), L.ptr(hz), L.ptr(sv), L.ptr(y), L.ptr(dhz), L.ptr(dsv),
-            L.ptr(dy), L.ptr(d_hcat), ga, ph, L.ptr(ws), ws.numel(), L.stream_of(hcat)), "mpo_fusion_head_backward"),
-            ws, hcat.device, ctx.param_refs, grads)
-        for t in (saved, hcat):
-            _keep_for_side(t)
+            L.ptr(dy), L.ptr(d_hcat), ga, L.ptr(ws), ws.numel(), L.stream_of(hcat)), "mpo_fusion_head_backward")
         return (d_hcat, *grads)
 
 

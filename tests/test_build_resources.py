@@ -7,7 +7,7 @@ import importlib
 
 import pytest
 
-_build = importlib.import_module("multimodal-path-omic_amd._build")
+_build = importlib.import_module("multimodal_path_omic_amd._build")
 
 # Known debt, bytes of scratch per lane allowed.  E=512 ('big' config) and the fp32-bag backward at E=256 exceed the
 # 512-register budget of one wave per SIMD; they are parity cases, not bench configurations.
