@@ -5,26 +5,33 @@ tokens), one process per GPU, RCCL gradient all-reduce once per optimiser step.
 
 A "step" = one gradient-accumulation window of --window slides per rank pushed through the model as
 one ragged batch (loss = ces, models/loss.py:5-28), gradients all-reduced, Adam step.  Prints ONE
-JSON line (rank 0) with the contract fields plus `roofline` (the K1 bag-pass kernel timed by HIP
-events on its own stream against algorithmic bytes) and `cpu_baseline` (the CPU oracle timed on
-this box's host cores on a bounded sample, N=1 only).
+JSON line (rank 0) with the contract fields plus `roofline` (the model's long-bag cross-attention
+kernel timed by HIP events on its own stream against algorithmic bytes), `cpu_baseline` (the CPU
+oracle timed on this box's host cores on a bounded sample, N=1 only) and `extra`: the same
+measurement for the other BASELINE configs (cfg 3 NaCAGaT 15k, cfg 4 ragged 2k-30k windows, cfg 5
+100k-patch fp32 bags), each with its own roofline.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(torch.distributed.run, 127.0.0.1) BEFORE this process touches the GPU, relays their output and exits
+with their status; under the driver's torch.distributed.run launch every rank runs main() directly.
 """
 import argparse
+import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BASE_SEED = 1234               # SURVEY 8(d): synthetic inputs from seed 1234 + config index / rank
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -38,16 +45,42 @@ def parse():
                     help="BASELINE cfg 4: bag lengths drawn uniformly from [2000, 30000] (fixed multiset, length-aware "
                          "assignment of each window's slides to ranks) instead of --patches for every slide")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline configuration only")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured HIP graph")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def build_model(kind, dev, bag_dtype):
+# ------------------------------------------------------------------------------------------------ self-launch
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a, argv):
+    """--gpus N > 1 without a torch.distributed environment: start N fresh rank processes.  Nothing in this process
+    has touched the GPU yet (torch is not even imported), and it is not replaced: it waits for the children."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+# ------------------------------------------------------------------------------------------------ workload
+def build_model(kind, dev, bag_dtype, rank):
+    """Weights: module default init under torch.manual_seed(0) on EVERY rank (replicas start identical; FlatAdam's flat
+    parameter buffer is additionally broadcast from rank 0).  Afterwards the generator is re-seeded per rank: the Philox
+    seed of every dropout stream is torch.initial_seed() (ops._reserve), so ranks draw different masks."""
+    import torch
     from multimodal_path_omic_amd.models import (MultimodalCoAttentionTransformer,
                                                  NarrowContextualAttentionGateTransformer)
     torch.manual_seed(0)
     cls = MultimodalCoAttentionTransformer if kind == "mcat" else NarrowContextualAttentionGateTransformer
-    return cls(omic_sizes=[256] * 6, model_size="medium", bag_dtype=bag_dtype).to(dev).train()
+    model = cls(omic_sizes=[256] * 6, model_size="medium", bag_dtype=bag_dtype).to(dev).train()
+    torch.manual_seed(BASE_SEED + 1000 * (rank + 1))
+    return model
 
 
 def make_windows(n_windows, window, patches, dev, bag_dtype, seed, ragged=False, rank=0, world=1):
@@ -55,6 +88,7 @@ def make_windows(n_windows, window, patches, dev, bag_dtype, seed, ragged=False,
     (i mod 4, i mod 2) as SURVEY 8(d) prescribes.  ragged: every window is a fixed multiset of world*window bag
     lengths in [2000, 30000] (the same at every GPU count for a given global window), dealt to the ranks by
     dp.assign_slides (longest-first bin packing on patch count); this rank keeps its share."""
+    import torch
     from multimodal_path_omic_amd.dp import assign_slides
     from multimodal_path_omic_amd.ops import BagBatch, make_cu
     from multimodal_path_omic_amd.synthetic import slide_lengths
@@ -80,6 +114,7 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
     """Time the model's cross-attention forward bag-pass kernel alone (HIP events on the launching stream) over a
     window of bags; algorithmic bytes = M*d*e per slide.  MCAT: K1's coattn_fwd_partial over H_bag in
     the bag dtype.  NaCAGaT: K2's bag_rowdot_gated over the key bag, which is fp32 whatever the bag dtype (e = 4)."""
+    import torch
     from multimodal_path_omic_amd import _lib as L
     from multimodal_path_omic_amd.ops import BagBatch, make_cu
     E, n_q = 256, 6
@@ -126,19 +161,24 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
     avg_us = sum(us) / len(us)
     alg_bytes = window * patches * E * esz
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    traffic, mfma_util = None, None
-    tpath = os.path.join(ROOT, "profiles", "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json")
+    # PMC-derived fields come from a STORED profile of this kernel on this configuration (profiles/*.json; separate
+    # rocprofv3 --pmc passes, FETCH_SIZE x 2 per the gfx950 correction), not from this run: labelled as such
+    traffic, mfma_util, source = None, None, None
+    tname = "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and window == 32 and patches == 15000 and (k2 or esz == 2):   # the configuration it was collected on
         with open(tpath) as f:
             prof = json.load(f)
         traffic = prof.get("hbm_bytes_per_launch")
         busy = prof.get("mfma", {}).get("SQ_VALU_MFMA_BUSY_CYCLES")
+        source = "profiles/" + tname
         if busy:                      # PMC busy cycles (summed over SIMDs) against this run's measured launch time
             mfma_util = round(busy / (4 * 256 * avg_us * 1e-6 * 2.4e9), 4)
     name = "bag_rowdot_gated_kernel<256,f32 key bag>" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
     return {"bound": "hbm", "kernel": name,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_util": mfma_util,
+            "traffic_source": source,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_us, 2),
             "min_launch_us": round(us[0], 2), "launches_timed": reps * burst, "launches_per_event_pair": burst}
 
@@ -147,6 +187,7 @@ def cpu_baseline_leg(kind, patches, budget_s=15.0):
     """The CPU oracle (kind 'port': PyTorch-CPU restatement pinned to the reference by golden
     vectors) on this box's host cores: whole-model forward + ces + backward, fp32, one slide at a
     time like the reference loop."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import cases as C
     from multimodal_path_omic_amd import synthetic as syn
@@ -176,31 +217,21 @@ def cpu_baseline_leg(kind, patches, budget_s=15.0):
             "sample": f"{n} slides of {patches}x1024 fp32, {kind} medium, fwd+ces+bwd, one slide per call"}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL.  MPO_DIST_BACKEND=gloo exists to rehearse the N > 1 code path with several ranks sharing
-        # one card (RCCL refuses two ranks on the same device); the driver's runs never set it.
-        dist.init_process_group(os.environ.get("MPO_DIST_BACKEND", "nccl"))
-    if a.gpus != world and rank == 0:
-        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {a.gpus} "
-              f"(running with {world} rank(s))", file=sys.stderr)
-    dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
-    torch.cuda.set_device(dev)
-    bag_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-
+def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
+    """Build the model and its resident windows, time `steps` window steps (barrier + synchronize on both sides, max over
+    ranks) and return the contract dict (rank 0; None elsewhere)."""
+    import torch
+    import torch.distributed as dist
     from multimodal_path_omic_amd.dp import FlatAdam, FlatGradBucket
     from multimodal_path_omic_amd.harness import GraphedWindowStep, train_window
-    model = build_model(a.model, dev, bag_dtype)
+    bag_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = build_model(a.model, dev, bag_dtype, rank)
     bucket = FlatGradBucket(list(model.parameters()))
     opt = FlatAdam(bucket, lr=2e-4, weight_decay=1e-5)            # adam, lr 2e-4, wd 1e-5: config.yaml:57-63
-    windows = make_windows(a.n_windows, a.window, a.patches, dev, bag_dtype, seed=1234 + rank, ragged=a.ragged,
+    if world > 1:
+        dist.broadcast(opt.flat_p, src=0)                         # replicas start from rank 0's weights
+    windows = make_windows(a.n_windows, a.window, a.patches, dev, bag_dtype, seed=BASE_SEED + rank, ragged=a.ragged,
                            rank=rank, world=world)
-    slides_per_step = [len(w[0].lengths) for w in windows]
 
     def eager_step(i):
         bags, omics, labels, cens = windows[i % len(windows)]
@@ -243,14 +274,14 @@ def main():
                     h.wait()
             opt.step()
 
-    for i in range(a.warmup):
+    for i in range(warmup):
         step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -259,25 +290,78 @@ def main():
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
+    out = None
     if rank == 0:
-        if a.ragged:          # ranks hold different slide counts per window; the global window is world * window slides
-            slides = sum(world * a.window for i in range(a.steps))
-        else:
-            slides = world * a.window * a.steps
+        slides = world * a.window * steps            # (ragged: ranks hold different counts; the global window is world * window)
         out = {
             "metric": "slides/sec (fwd+bwd) at 15k-patch bags", "value": round(slides / dt, 2), "unit": "slides/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"{a.model.upper()} medium whole model fwd+bwd+Adam, {a.patches}x1024 {a.dtype} patch bag "
+            "config": {"workload": f"{a.model.upper()} medium whole model fwd+bwd+Adam, "
+                                   f"{'2k-30k' if a.ragged else a.patches}x1024 {a.dtype} patch bag "
                                    f"+ 6x256 omic tokens per slide, ces loss", "slides_per_rank_per_step": a.window,
                        "global_slides_per_step": world * a.window,
                        "patches_per_slide": "uniform[2000,30000] (fixed multiset)" if a.ragged else a.patches,
                        "parallelism": f"dp{world}", "resident_windows": a.n_windows, "launch": graph_note},
         }
-        out["roofline"] = roofline_leg(dev, a.window, a.patches, bag_dtype, a.model)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_leg(a.model, a.patches)
+    # release this configuration's graphs and windows before the next one is built
+    del graphed, windows, opt, bucket, model
+    gc.collect()
+    torch.cuda.empty_cache()
+    if rank == 0 and with_roofline:
+        out["roofline"] = roofline_leg(dev, a.window, a.patches if not a.ragged else 16000, bag_dtype, a.model)
+        torch.cuda.empty_cache()
+    return out
+
+
+def extras(a, dev, rank, world):
+    """The other BASELINE configs as `extra` entries of the same line: cfg 4 (ragged windows; at every N, it is the
+    data-parallel config), and at N = 1 also cfg 3 (NaCAGaT) and cfg 5 (100k-patch fp32 bags, window 8)."""
+    plan = [("cfg4_ragged_2k_30k", dict(model=a.model, ragged=True, patches=15000, dtype="bf16", window=32, n_windows=2), False)]
+    if world == 1:
+        plan += [("cfg3_nacagat_15k", dict(model="nacagat", ragged=False, patches=15000, dtype="bf16", window=32, n_windows=2), True),
+                 ("cfg5_mcat_100k_fp32", dict(model="mcat", ragged=False, patches=100000, dtype="f32", window=8, n_windows=2), True)]
+    out = {}
+    for name, over, roof in plan:
+        b = argparse.Namespace(**{**vars(a), **over})
+        try:
+            r = run_config(b, dev, rank, world, steps=max(5, min(a.steps, 10)), warmup=2, with_roofline=roof)
+        except Exception as e:                                    # an extra must never take the headline line down
+            r = {"error": f"{type(e).__name__}: {str(e)[:200]}"} if rank == 0 else None
+        if rank == 0:
+            out[name] = r
+    return out
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, argv))
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # "nccl" is RCCL.  MPO_DIST_BACKEND=gloo exists to rehearse the N > 1 code path with several ranks sharing
+        # one card (RCCL refuses two ranks on the same device); the driver's runs never set it.
+        dist.init_process_group(os.environ.get("MPO_DIST_BACKEND", "nccl"))
+    if a.gpus != world and rank == 0:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE is {world}: reporting n_gpus = {world}", file=sys.stderr)
+    dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
+    torch.cuda.set_device(dev)
+
+    out = run_config(a, dev, rank, world, a.steps, a.warmup)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_leg(a.model, a.patches)
+    if not a.no_extras and not a.ragged and a.model == "mcat" and a.patches == 15000 and a.dtype == "bf16":
+        ex = extras(a, dev, rank, world)
+        if rank == 0:
+            out["extra"] = ex
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -50,6 +50,14 @@ class FlatGradBucket:
                 continue
             p.grad = view.view(p.shape)
 
+    def head_numel(self, param) -> int:
+        """Number of leading bucket elements owned by `param`, which must be the FIRST parameter of the bucket (the
+        split exchange reduces flat[head:] while the patch layer's weight gradient, flat[:head], is still being
+        computed).  Raises if the layout assumption does not hold."""
+        if param._mpo_grad_view.data_ptr() != self.flat.data_ptr():
+            raise RuntimeError("split exchange: the patch layer's weight (H.0.weight) must lead the gradient bucket")
+        return param.numel()
+
     def zero(self):
         self.flat.zero_()
         for p in self.params:

@@ -126,11 +126,19 @@ class GraphedWindowStep:
         if ops._rng_epoch_tensor is None:
             ops.set_rng_epoch(torch.zeros(1, dtype=torch.int64, device=dev))
         self.epoch = ops._rng_epoch_tensor
+        # warm-up runs execute real steps (allocator, lazy initialisation): construction must not train the model, so the
+        # optimiser state they touch is put back afterwards (the capture itself executes nothing)
+        keep = None if opt is None else [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.t_dev)]
+        keep_epoch = self.epoch.clone()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._body()
+            if keep is not None:
+                for t, k in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.t_dev), keep):
+                    t.copy_(k)
+            self.epoch.copy_(keep_epoch)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other threads (RCCL's watchdog under torch.distributed) may issue HIP calls meanwhile
@@ -161,9 +169,7 @@ class GraphedWindowStep:
 
     def head_numel(self) -> int:
         """Number of leading bucket elements that only replay_tail() writes (the patch layer's weight)."""
-        p = self.model.H[0].weight
-        assert p._mpo_grad_view.data_ptr() == self.bucket.flat.data_ptr(), "H.0.weight must lead the gradient bucket"
-        return p.numel()
+        return self.bucket.head_numel(self.model.H[0].weight)
 
     def replay_tail(self):
         if self.tail_graph is not None:

@@ -87,6 +87,7 @@ class _Slot:
         self.ready = torch.cuda.Event()          # H2D of this slot finished
         self.free = torch.cuda.Event()           # consumer finished with this slot
         self.free_recorded = False
+        self.shipped = False                     # `ready` has been recorded at least once
 
 
 class WindowFeeder:
@@ -117,6 +118,13 @@ class WindowFeeder:
         for m in lengths:
             offs.append(offs[-1] + m)
 
+        # The slab is about to be overwritten: the H2D copy of the window it held before must have LEFT it.  That copy
+        # waits (on the device) for the consumer of a still older window, so when the GPU lags the host by a ring's worth
+        # of windows it may not even have started -- every other ordering here is device-side.  Block THIS packer thread
+        # (never the consumer) until the slab's last copy is done.
+        if slot.shipped:
+            slot.ready.synchronize()
+
         def one(k):
             src = self.store.load(ids[k])
             if src.shape != (lengths[k], self.feat):
@@ -128,6 +136,7 @@ class WindowFeeder:
                 self.copy_stream.wait_event(slot.free)         # the consumer must be done with the slot's old window
             slot.dev[:offs[-1]].copy_(slot.host[:offs[-1]], non_blocking=True)
             slot.ready.record(self.copy_stream)
+            slot.shipped = True
         return lengths
 
     def _submit(self, w: int):

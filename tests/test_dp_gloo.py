@@ -91,3 +91,99 @@ def test_bucket_views_alias_param_grads():
     torch.testing.assert_close(bucket.flat, 2 * ref)
     bucket.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in model.parameters())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The REAL model's parameter layout through the bucket, the flat optimiser buffers and the split exchange of the
+# data-parallel step (bench.py / harness.GraphedWindowStep(split_patch_grad=True)): flat[head:] is reduced while the
+# patch layer's weight gradient flat[:head] is still being computed, then flat[:head].  CPU tensors + gloo: the bucket
+# logic needs no kernel (the HIP kernels are covered on one GPU by tests/test_gpu_graph.py, and the whole step at
+# world size 2 by tests/test_gpu_dp.py).
+def _real_model():
+    from multimodal_path_omic_amd.models import MultimodalCoAttentionTransformer
+    torch.manual_seed(0)
+    return MultimodalCoAttentionTransformer(omic_sizes=[32, 48, 64], model_size="small")
+
+
+def _synthetic_grads(n, rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(n, generator=g)
+
+
+def _real_worker(rank, world, port, out):
+    from multimodal_path_omic_amd.dp import FlatAdam
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _real_model()
+    bucket = FlatGradBucket(list(model.parameters()))
+    opt = FlatAdam(bucket, lr=1e-3)                       # construction is pure torch: parameters re-pointed at flat_p
+    dist.broadcast(opt.flat_p, src=0)
+    head = bucket.head_numel(model.H[0].weight)
+    n = bucket.flat.numel()
+    bucket.begin()
+    bucket.finish()                                       # nothing ran: every slice zero-filled, .grad re-attached
+    assert float(bucket.flat.abs().sum()) == 0.0
+    bucket.flat.copy_(_synthetic_grads(n, rank))
+    bucket.flat[:head].zero_()                            # "the main graph has run": everything but dW_H is there
+    rest = bucket.all_reduce_mean_async(lo=head)
+    bucket.flat[:head].copy_(_synthetic_grads(n, rank)[:head])     # "the tail graph": dW_H lands while `rest` is in flight
+    first = bucket.all_reduce_mean_async(lo=0, hi=head)
+    for h in (rest, first):
+        h.wait()
+    if rank == 0:
+        torch.save({"flat": bucket.flat.clone(), "head": head,
+                    "grad_H": model.H[0].weight.grad.clone(), "grad_cls": model.classifier.bias.grad.clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_split_exchange_on_real_parameter_layout(tmp_path):
+    world, port, out = 2, _free_port(), str(tmp_path / "real.pt")
+    mp.spawn(_real_worker, args=(world, port, out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=True)
+    model = _real_model()
+    n = sum(p.numel() for p in model.parameters())
+    want = sum(_synthetic_grads(n, r) for r in range(world)) / world
+    torch.testing.assert_close(got["flat"], want, rtol=1e-6, atol=1e-7)
+    assert got["head"] == model.H[0].weight.numel() == 1024 * 128
+    # parameter .grad tensors ARE the bucket slices (first and last parameter of the model)
+    torch.testing.assert_close(got["grad_H"].flatten(), want[:got["head"]])
+    torch.testing.assert_close(got["grad_cls"].flatten(), want[-model.classifier.bias.numel():])
+
+
+def test_flat_adam_repoints_parameters_and_keeps_state_dict():
+    from multimodal_path_omic_amd.dp import FlatAdam
+    model = _real_model()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    bucket = FlatGradBucket(list(model.parameters()))
+    opt = FlatAdam(bucket, lr=1e-3)
+    after = model.state_dict()
+    assert list(before) == list(after)
+    for k in before:
+        torch.testing.assert_close(before[k], after[k], rtol=0, atol=0)
+    off = 0
+    for p in model.parameters():                          # every parameter is a view of the flat buffer, in bucket order
+        assert p.data_ptr() == opt.flat_p.data_ptr() + 4 * off
+        off += p.numel()
+    assert off == opt.flat_p.numel() == bucket.flat.numel()
+    opt.flat_p.add_(1.0)                                  # an update of the flat buffer IS an update of the model
+    torch.testing.assert_close(model.classifier.bias.detach(), before["classifier.bias"] + 1.0)
+    with pytest.raises(RuntimeError):                     # the update kernel is HIP: no CPU fallback
+        opt.step()
+
+
+def test_bucket_slice_is_handed_out_once_per_window():
+    """ops.grad_out: the kernels OVERWRITE their gradient outputs, so a parameter's bucket slice may be handed to one
+    producer per window only; a second producer gets a private tensor (autograd then adds the two)."""
+    from multimodal_path_omic_amd import ops
+    model = _model()
+    bucket = FlatGradBucket(list(model.parameters()))
+    p = next(model.parameters())
+    bucket.begin()
+    a = ops.grad_out(p)
+    b = ops.grad_out(p)
+    assert a.data_ptr() == p._mpo_grad_view.data_ptr()
+    assert b.data_ptr() != a.data_ptr()
+    bucket.begin()                                        # next window: the slice is available again
+    assert ops.grad_out(p).data_ptr() == p._mpo_grad_view.data_ptr()

@@ -56,3 +56,22 @@ def test_feeder_reports_a_bad_slide(dev):
         for _ in feeder:
             pass
     feeder.close()
+
+
+def test_feeder_keeps_slabs_intact_when_the_gpu_lags(dev):
+    """The consumer's stream is stalled by a long kernel per window, so the packer runs a whole ring ahead of the GPU:
+    a pinned slab must not be refilled before its previous H2D copy has left it (the copy itself is queued behind the
+    stalled consumer).  Every window must still arrive bit-exact."""
+    slides, omics, labels, cens = _cohort(24, 3)
+    order = list(range(24))
+    feeder = WindowFeeder(ArrayStore(slides), order, window=2, device=dev, bag_dtype=torch.bfloat16, depth=2, workers=4,
+                          omics_of=lambda ids: [], labels_of=lambda ids: labels[ids], cens_of=lambda ids: cens[ids])
+    sums, refs = [], []
+    for bags, _, _, _, ids in feeder:                                # 12 windows through a ring of 3 slabs
+        torch.cuda._sleep(40_000_000)                                # ~20 ms of GPU time in front of every use
+        sums.append(bags.data.clone())                               # consumed on the (late) compute stream
+        refs.append(torch.cat([slides[i] for i in ids]).to(torch.bfloat16))
+    torch.cuda.synchronize(dev)
+    for got, ref in zip(sums, refs):
+        assert torch.equal(got.cpu(), ref)
+    feeder.close()

@@ -96,6 +96,50 @@ def test_model_bf16_bag_within_north_star(dev, kind):
         assert err < (2e-2 if n.startswith("H.") else 1e-2), (n, err)
 
 
+@pytest.mark.parametrize("case", ["mcat_m15000", "nacagat_m15000", "mcat_m2000", "nacagat_m2000"])
+def test_model_bf16_bag_vs_fp32_reference_golden(dev, golden, case, record_property):
+    """The BENCHMARKED storage mode at the benchmarked bag length against the fp32 REFERENCE's own outputs (fixtures
+    generated by the imported reference, tests/golden/make_golden.py): bf16 patch matrix, bf16 patch-layer operands and
+    bf16 H_bag, fp32 accumulation, fp32 6 x d tail.
+      * hazards / survs / Y: the north_star bar, 1e-3 absolute.
+      * co-attention map: element-wise RELATIVE error.  Rounding the 15 000 x 1024 patch matrix to bf16
+        ALONE -- fp32 arithmetic everywhere else, measured with the CPU oracle on these fixtures -- already moves the map
+        by 3.1e-3 (MCAT) / 2.9e-2 (NaCAGaT: the narrow gate multiplies the logit error), so 1e-3 on the map is not
+        reachable in this storage mode by any kernel.  What the kernels must NOT do is add to the storage rounding: the
+        error against the fp32 reference is held to the error the ORACLE makes when it is fed the same stored values
+        (bag_storage=bf16; fp32 arithmetic), +25 %, and the map is held to 1e-3 against that same-storage oracle.
+    The measured margins are printed (pytest -rA) and quoted in DESIGN.md section 4."""
+    g = golden("models")
+    kind, m, omic_sizes, seed = C.MODEL_CASES[case]
+    model, sd = build(kind, omic_sizes, seed, dev, bag_dtype=torch.bfloat16)
+    wsi, omics, label, censor = C.model_inputs(m, omic_sizes, seed + 1)
+    kw = dict(inference=True) if kind == "mcat" else {}
+    hz, sv, y, att = model(wsi=wsi.to(dev), omics=[o.to(dev) for o in omics], **kw)
+    ga = g[f"{case}/A_coattn_sub"]
+
+    def map_rel(a, ref):
+        return float(((a - ref).abs() / ref.clamp_min(1e-30)).max())
+    e_h = float((hz.detach().cpu() - g[f"{case}/hazards"]).abs().max())
+    e_s = float((sv.cpu() - g[f"{case}/survs"]).abs().max())
+    e_y = float((y.cpu() - g[f"{case}/Y"]).abs().max())
+    e_a = map_rel(sub(att["coattn"]).cpu(), ga)
+    e_p = relerr(att["path"], g[f"{case}/A_path"])
+    fwd = O.mcat_forward if kind == "mcat" else O.nacagat_forward
+    with torch.no_grad():
+        _, _, _, att_s = fwd(sd, wsi, omics, bag_storage=torch.bfloat16, **kw)       # same stored values, fp32 arithmetic
+        _, _, _, att_x = fwd(sd, wsi.bfloat16().float(), omics, **kw)                # ONLY the patch matrix rounded
+    floor_s, floor_x = map_rel(sub(att_s["coattn"]), ga), map_rel(sub(att_x["coattn"]), ga)
+    e_same = map_rel(sub(att["coattn"]).cpu(), sub(att_s["coattn"]))
+    print(f"[bf16 vs fp32 reference] {case}: hazards {e_h:.2e} survs {e_s:.2e} Y {e_y:.2e} path map rel {e_p:.2e} | coattn map rel "
+          f"{e_a:.2e} (oracle on the same stored values {floor_s:.2e}; patch matrix rounded alone {floor_x:.2e}); vs same-storage oracle {e_same:.2e}")
+    for k, v in (("hazards", e_h), ("survs", e_s), ("Y", e_y), ("coattn_rel", e_a), ("coattn_rel_storage_floor", floor_s),
+                 ("coattn_rel_patch_rounding_only", floor_x), ("coattn_rel_vs_same_storage_oracle", e_same), ("path_rel", e_p)):
+        record_property(f"{case}/{k}", v)
+    assert e_h < 1e-3 and e_s < 1e-3 and e_y < 1e-3, (e_h, e_s, e_y)
+    assert e_a < 1.25 * floor_s + 2e-4, (e_a, floor_s)
+    assert e_same < 1e-3, e_same
+
+
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])
 @pytest.mark.parametrize("lengths", [[300, 1, 2048, 77], [30000] + [40] * 15 + [7] * 16], ids=["mixed", "one_giant_31_tiny"])
 def test_window_equals_per_slide(dev, kind, lengths):
