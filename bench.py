@@ -110,46 +110,16 @@ def make_windows(n_windows, window, patches, dev, bag_dtype, seed, ragged=False,
     return out
 
 
-def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
-    """Time the model's cross-attention forward bag-pass kernel alone (HIP events on the launching stream) over a
-    window of bags; algorithmic bytes = M*d*e per slide.  MCAT: K1's coattn_fwd_partial over H_bag in
-    the bag dtype.  NaCAGaT: K2's bag_rowdot_gated over the key bag, which is fp32 whatever the bag dtype (e = 4)."""
+def _time_launches(dev, launch, reps, burst=4):
+    """HIP-event timing on the launching stream.  One event pair brackets a burst of back-to-back launches (alternating
+    resident inputs): a pair around a single launch also times that launch's dispatch latency (~3 us, which rocprofv3's
+    kernel duration does not contain); inside a burst the next dispatch overlaps the running kernel, as it does in the
+    captured window step.  Returns sorted per-launch microseconds."""
     import torch
-    from multimodal_path_omic_amd import _lib as L
-    from multimodal_path_omic_amd.ops import BagBatch, make_cu
-    E, n_q = 256, 6
-    k2 = kind == "nacagat"
-    store = torch.float32 if k2 else bag_dtype
-    esz = 4 if store == torch.float32 else 2
-    lengths = [patches] * window
-    cu = make_cu(lengths, dev)
-    bags = [torch.relu(torch.randn(window * patches, E, device=dev)).to(store) for _ in range(2)]
-    batch = BagBatch(bags[0], cu, lengths)
-    plan = batch.plan()
-    qk2 = torch.randn(window * n_q, E, device=dev) * 0.05
-    tq = torch.tanh(torch.randn(window * n_q, E, device=dev))
-    lib = L.lib()
-    parts = lib.mpo_coattn_target_workgroups() + window
-    part_ml = torch.empty(parts * 32, device=dev)
-    part_ctx = torch.empty(parts * n_q * E, device=dev)
-    maps = torch.empty(2, n_q * window * patches, device=dev) if k2 else None
     stream = torch.cuda.current_stream(dev)
-
-    def launch(i):
-        if k2:
-            L.check(lib.mpo_nacagat_fwd_bagpass(L.ptr(bags[i & 1]), L.ptr(cu), window, E, L.ptr(qk2), L.ptr(tq), L.ptr(maps[0]),
-                                                L.ptr(maps[1]), n_q, patches, plan, stream.cuda_stream), "mpo_nacagat_fwd_bagpass")
-        else:
-            L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), L.bag_dtype_code(bags[0]), L.ptr(cu), window, E,
-                                               L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, patches, plan,
-                                               stream.cuda_stream), "mpo_coattn_fwd_bagpass")
     for i in range(3):
         launch(i)
     torch.cuda.synchronize(dev)
-    # one event pair brackets a burst of `burst` back-to-back launches (alternating resident bags): a pair around a
-    # single launch also times that launch's dispatch latency (~3 us, which rocprofv3's kernel duration does not contain);
-    # inside a burst the next dispatch overlaps the running kernel, as it does in the captured window step
-    burst = 4
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for i, (s, e) in enumerate(evs):
         s.record(stream)
@@ -157,24 +127,87 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
             launch(i * burst + j)
         e.record(stream)
     torch.cuda.synchronize(dev)
-    us = sorted(s.elapsed_time(e) * 1e3 / burst for s, e in evs)
+    return sorted(s.elapsed_time(e) * 1e3 / burst for s, e in evs), burst
+
+
+def _stored_profile(name, avg_us, applies):
+    """PMC-derived fields come from a STORED profile of the same kernel on the same configuration (profiles/<name>:
+    separate rocprofv3 --pmc passes, FETCH_SIZE x 2 per the gfx950 correction), not from this run: labelled as such."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not (applies and os.path.exists(path)):
+        return None, None, None
+    with open(path) as f:
+        prof = json.load(f)
+    busy = prof.get("mfma", {}).get("SQ_VALU_MFMA_BUSY_CYCLES")
+    # PMC busy cycles (summed over SIMDs) against this run's measured launch time
+    util = round(busy / (4 * 256 * avg_us * 1e-6 * 2.4e9), 4) if busy else None
+    return prof.get("hbm_bytes_per_launch"), util, "profiles/" + name
+
+
+def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
+    """Time the model's long-bag cross-attention forward kernel alone over a window of bags against its ALGORITHMIC bytes
+    (DESIGN.md section 3):
+      MCAT, bf16 window (the headline): the fused patch-layer + co-attention pass (row f1): reads the raw patch matrix
+        once, writes H_bag once: M * (1024 + 256) * 2 bytes per slide;
+      MCAT, fp32 window: K1's coattn_fwd_partial over H_bag, M * 256 * 4 bytes per slide;
+      NaCAGaT: K2's bag_rowdot_gated over the key bag, fp32 whatever the bag dtype: M * 256 * 4 bytes per slide."""
+    import torch
+    from multimodal_path_omic_amd import _lib as L
+    from multimodal_path_omic_amd.ops import BagBatch, make_cu
+    E, n_q = 256, 6
+    lib = L.lib()
+    lengths = [patches] * window
+    cu = make_cu(lengths, dev)
+    stream = torch.cuda.current_stream(dev)
+    parts = lib.mpo_coattn_target_workgroups() + window
+    part_ml = torch.empty(parts * 32, device=dev)
+    part_ctx = torch.empty(parts * n_q * E, device=dev)
+    qk2 = torch.randn(window * n_q, E, device=dev) * 0.05
+    fused = kind == "mcat" and bag_dtype == torch.bfloat16
+    if fused:
+        xs = [torch.randn(window * patches, 1024, device=dev).to(torch.bfloat16) for _ in range(2)]
+        batch = BagBatch(xs[0], cu, lengths)
+        plan = batch.plan()
+        w = torch.randn(E, 1024, device=dev) / 32
+        wb = torch.empty(E, 1024, device=dev, dtype=torch.bfloat16)
+        L.check(lib.mpo_cast_bf16(L.ptr(w), L.ptr(wb), w.numel(), stream.cuda_stream), "mpo_cast_bf16")
+        bias = torch.randn(E, device=dev) * 0.1
+        h_out = torch.empty(window * patches, E, device=dev, dtype=torch.bfloat16)
+
+        def launch(i):
+            L.check(lib.mpo_patch_coattn_fwd_bagpass(L.ptr(xs[i & 1]), L.ptr(wb), L.ptr(bias), L.ptr(cu), window, L.ptr(qk2),
+                                                     L.ptr(h_out), L.ptr(part_ml), L.ptr(part_ctx), n_q, patches, 0.25, 1, 0,
+                                                     plan, stream.cuda_stream), "mpo_patch_coattn_fwd_bagpass")
+        alg_bytes = window * patches * (1024 + E) * 2
+        name = "patch_coattn_fwd_kernel<1024->256, bf16>"
+        tname = "f1_fwd_traffic.json"
+        applies = window == 32 and patches == 15000
+    else:
+        k2 = kind == "nacagat"
+        store = torch.float32 if k2 else bag_dtype
+        esz = 4 if store == torch.float32 else 2
+        bags = [torch.relu(torch.randn(window * patches, E, device=dev)).to(store) for _ in range(2)]
+        batch = BagBatch(bags[0], cu, lengths)
+        plan = batch.plan()
+        tq = torch.tanh(torch.randn(window * n_q, E, device=dev))
+        maps = torch.empty(2, n_q * window * patches, device=dev) if k2 else None
+
+        def launch(i):
+            if k2:
+                L.check(lib.mpo_nacagat_fwd_bagpass(L.ptr(bags[i & 1]), L.ptr(cu), window, E, L.ptr(qk2), L.ptr(tq), L.ptr(maps[0]),
+                                                    L.ptr(maps[1]), n_q, patches, plan, stream.cuda_stream), "mpo_nacagat_fwd_bagpass")
+            else:
+                L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(bags[i & 1]), L.bag_dtype_code(bags[0]), L.ptr(cu), window, E,
+                                                   L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, patches, plan,
+                                                   stream.cuda_stream), "mpo_coattn_fwd_bagpass")
+        alg_bytes = window * patches * E * esz
+        name = "bag_rowdot_gated_kernel<256,f32 key bag>" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
+        tname = "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json"
+        applies = window == 32 and patches == 15000 and (k2 or esz == 2)
+    us, burst = _time_launches(dev, launch, reps)
     avg_us = sum(us) / len(us)
-    alg_bytes = window * patches * E * esz
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    # PMC-derived fields come from a STORED profile of this kernel on this configuration (profiles/*.json; separate
-    # rocprofv3 --pmc passes, FETCH_SIZE x 2 per the gfx950 correction), not from this run: labelled as such
-    traffic, mfma_util, source = None, None, None
-    tname = "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json"
-    tpath = os.path.join(ROOT, "profiles", tname)
-    if os.path.exists(tpath) and window == 32 and patches == 15000 and (k2 or esz == 2):   # the configuration it was collected on
-        with open(tpath) as f:
-            prof = json.load(f)
-        traffic = prof.get("hbm_bytes_per_launch")
-        busy = prof.get("mfma", {}).get("SQ_VALU_MFMA_BUSY_CYCLES")
-        source = "profiles/" + tname
-        if busy:                      # PMC busy cycles (summed over SIMDs) against this run's measured launch time
-            mfma_util = round(busy / (4 * 256 * avg_us * 1e-6 * 2.4e9), 4)
-    name = "bag_rowdot_gated_kernel<256,f32 key bag>" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
+    traffic, mfma_util, source = _stored_profile(tname, avg_us, applies)
     return {"bound": "hbm", "kernel": name,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_util": mfma_util,

@@ -78,6 +78,33 @@ int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_ro
                             const float* out_proj_weight, const float* out_proj_bias,
                             float* out, float* attn_map, float* saved, const mpo_bag_plan* plan /* nullable */,
                             void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+/* ---- row f1: the patch layer fused with K1's forward, ONE pass over the raw patch matrix.
+ * Replaces models/mcat/mcat.py:24-29,87 (self.H = Linear(1024, 256) + ReLU + Dropout) AND :97 (the co-attention call) for a
+ * bf16-stored window:  h_bag = Dropout_p(ReLU(patches W_H^T + b_H))  is produced tile by tile on the MFMA, consumed for
+ * the scores / online softmax / context while it is still in LDS, and written once (bf16, [total_rows, embed]) for
+ * mpo_coattn_mcat_backward, which takes `saved` and h_bag exactly as after mpo_coattn_mcat_forward.
+ *   patches [total_rows, patch_dim] bf16;  patch_weight [embed, patch_dim] fp32 (rounded to bf16 operands inside),
+ *   patch_bias [embed] fp32.  Built for patch_dim 1024, embed 256 ('medium'), n_q <= 8.
+ * Dropout: Philox (seed, offset [+ *rng_epoch << 40]), one draw per 16 elements, 8 random bits each: the realised drop
+ * probability is round(256 p) / 256 (exact for the reference's 0.25) and the keep scale follows it; reserve
+ * total_rows * embed / 16 + 1 counters. */
+size_t mpo_patch_coattn_workspace_bytes(int n_slides, int n_q, int embed, int patch_dim);
+int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
+                                  int patch_dim, const float* patch_weight, const float* patch_bias, float drop_p,
+                                  uint64_t seed, uint64_t offset, const uint64_t* rng_epoch /* nullable */,
+                                  const float* query, int n_q, int embed,
+                                  const float* in_proj_weight, const float* in_proj_bias,
+                                  const float* out_proj_weight, const float* out_proj_bias,
+                                  void* h_bag, float* out, float* attn_map /* nullable */, float* saved,
+                                  const mpo_bag_plan* plan /* nullable */, void* workspace, size_t workspace_bytes,
+                                  mpo_stream_t stream);
+/* The fused bag pass alone (measurement): w_bf16 [embed, patch_dim] bf16 from mpo_cast_bf16, qk2 [n_slides*n_q, embed]. */
+int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_bf16, const float* bias, const int32_t* cu_rows, int n_slides,
+                                 const float* qk2, void* h_bag, float* part_ml, float* part_ctx, int n_q, int max_rows,
+                                 float drop_p, uint64_t seed, uint64_t offset, const mpo_bag_plan* plan /* nullable */,
+                                 mpo_stream_t stream);
+int mpo_cast_bf16(const float* in, void* out, int64_t n /* multiple of 4 */, mpo_stream_t stream);
+
 /* d_attn_map (nullable): gradient arriving on the returned map; needs attn_map from the forward.
  * d_bag has the bag's dtype.  d_in_proj_bias[embed..2*embed) (the key bias) is exactly zero: a key
  * bias shifts every logit of a row equally and cancels in the softmax. */

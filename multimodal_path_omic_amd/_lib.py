@@ -44,6 +44,12 @@ _SIGNATURES = {
     "mpo_coattn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mpo_coattn_mcat_forward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                         _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_patch_coattn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mpo_patch_coattn_mcat_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, c_uint64, c_uint64, _P,
+                                              _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_patch_coattn_fwd_bagpass": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, c_uint64,
+                                             _P, _P]),
+    "mpo_cast_bf16": (c_int, [_P, _P, ctypes.c_int64, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
     "mpo_colsum_bf16": (c_int, [_P, _P, ctypes.c_int64, c_int, _P]),

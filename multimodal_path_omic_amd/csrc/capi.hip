@@ -79,7 +79,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 7; }
+int mpo_abi_version(void) { return 8; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -163,6 +163,67 @@ int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_ro
     if (attn_map)
         if ((rc = mpo_launch_coattn_normalize(attn_map, lse2, cu_rows, n_slides, n_q, max_rows, 0.f, 0, 0, stream))) return rc;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------- row f1: patch layer + K1
+size_t mpo_patch_coattn_workspace_bytes(int n_slides, int n_q, int embed, int patch_dim) {
+    size_t f = 0;
+    f = arena_need(f, max_parts(n_slides) * 32);
+    f = arena_need(f, max_parts(n_slides) * n_q * embed);
+    f = arena_need(f, (size_t)embed * patch_dim / 2);           // W_H as bf16 (2 bytes per element)
+    return f + 256;
+}
+
+int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, int n_slides, int total_rows, int max_rows,
+                                  int patch_dim, const float* patch_weight, const float* patch_bias, float drop_p,
+                                  uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
+                                  const float* query, int n_q, int embed, const float* in_w, const float* in_b,
+                                  const float* out_w, const float* out_b, void* h_bag, float* out, float* attn_map,
+                                  float* saved, const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes,
+                                  mpo_stream_t stream) {
+    if (int rc = check_common(MPO_BF16, n_slides, total_rows, max_rows, n_q, embed)) return rc;
+    MPO_CHECK(embed == 256 && patch_dim == 1024, "fused patch layer + co-attention is built for 1024 -> 256 (got %d -> %d)",
+              patch_dim, embed);
+    const int E = embed, R = n_slides * n_q;
+    const BagPlan plan = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(plan, n_slides)) return rc;
+    Arena ws(workspace, workspace_bytes);
+    float* part_ml = ws.floats(plan_parts(plan) * 32);
+    float* part_ctx = ws.floats(plan_parts(plan) * n_q * E);
+    float* w_bf16 = ws.floats((size_t)E * patch_dim / 2);
+    MPO_CHECK(part_ml && part_ctx && w_bf16, "fused patch layer + co-attention: workspace too small (%zu bytes)", workspace_bytes);
+    float* qs = saved;                                     // same saved layout as mpo_coattn_mcat_forward: its backward applies
+    float* qk2 = qs + (size_t)R * E;
+    float* ctx = qk2 + (size_t)R * E;
+    float* attn = ctx + (size_t)R * E;
+    float* lse2 = attn + (size_t)R * E;
+    const float scale = 1.0f / sqrtf((float)E);
+    int rc;
+    if ((rc = mpo_launch_cast_bf16(patch_weight, w_bf16, (size_t)E * patch_dim, stream))) return rc;
+    if ((rc = mpo_linear_fwd(query, in_w, in_b, qs, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
+    if ((rc = mpo_linear_bwd_input(qs, in_w + (size_t)E * E, qk2, R, E, E, kLog2e, 0, stream))) return rc;
+    if ((rc = mpo_launch_patch_coattn_fwd(patches, w_bf16, patch_bias, cu_rows, qk2, h_bag, part_ml, part_ctx, attn_map, n_q,
+                                          drop_p, seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), plan,
+                                          stream))) return rc;
+    if ((rc = mpo_launch_coattn_combine(part_ml, part_ctx, ctx, lse2, n_slides, n_q, E, plan, stream))) return rc;
+    if ((rc = mpo_linear_fwd(ctx, in_w + (size_t)2 * E * E, in_b + 2 * E, attn, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
+    if ((rc = mpo_linear_fwd(attn, out_w, out_b, out, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
+    if (attn_map)
+        if ((rc = mpo_launch_coattn_normalize(attn_map, lse2, cu_rows, n_slides, n_q, max_rows, 0.f, 0, 0, stream))) return rc;
+    return 0;
+}
+
+// the fused bag pass alone (bench.py's roofline leg, profiling workloads)
+int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_bf16, const float* bias, const int32_t* cu_rows, int n_slides,
+                                 const float* qk2, void* h_bag, float* part_ml, float* part_ctx, int n_q, int max_rows,
+                                 float drop_p, uint64_t seed, uint64_t offset, const mpo_bag_plan* plan_, mpo_stream_t stream) {
+    const BagPlan plan = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(plan, n_slides)) return rc;
+    return mpo_launch_patch_coattn_fwd(patches, w_bf16, bias, cu_rows, qk2, h_bag, part_ml, part_ctx, nullptr, n_q, drop_p, seed,
+                                       offset, nullptr, plan, stream);
+}
+int mpo_cast_bf16(const float* in, void* out, int64_t n, mpo_stream_t stream) {
+    return mpo_launch_cast_bf16(in, out, (size_t)n, stream);
 }
 
 int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int total_rows,

@@ -75,6 +75,10 @@ class _FusionModelBase(nn.Module):
             h = F.dropout(torch.relu(F.linear(x.float(), lin.weight, lin.bias)), p, self.training)
         return bags.with_data(h)
 
+    def _patch_and_co_attend(self, g_bag, bags: BagBatch, inference: bool):
+        """Patch layer + co-attention (models/mcat/mcat.py:87,97).  Subclasses with a fused kernel override this."""
+        return self._co_attend(g_bag, self._patch_fc(bags), inference)
+
     def _omic_fc(self, omics: "List[torch.Tensor]") -> torch.Tensor:
         """omics: per group a (B, d_i) tensor -> G_bag (B, N, d)."""
         return ops.omic_snn(omics, self.G, self.training)
@@ -88,8 +92,7 @@ class _FusionModelBase(nn.Module):
         with grouped GEMMs (ops.encoder_stacked, ops.gated_pool_stacked): the token tail is a latency-bound chain of
         small launches, so the omic branch rides along in launches the path branch needs anyway."""
         g_bag = self._omic_fc(omics)
-        h_bags = self._patch_fc(bags)
-        h_coattn, a_coattn = self._co_attend(g_bag, h_bags, inference)
+        h_coattn, a_coattn = self._patch_and_co_attend(g_bag, bags, inference)
         tokens = ops.encoder_stacked(torch.stack([h_coattn, g_bag]),
                                      [list(self.path_transformer.layers), list(self.omic_transformer.layers)], self.training)
         a, h = ops.gated_pool_stacked(tokens, [self.path_attention_head, self.omic_attention_head],
@@ -140,6 +143,17 @@ class MultimodalCoAttentionTransformer(_FusionModelBase):
         if h_bags.data.dtype == torch.bfloat16:
             gate = 1.0 / (1.0 - self.H[2].p) if self.training else 1.0
         return self.co_attention.forward_window(g_bag, h_bags, need_weights=inference, bag_relu_gate=gate)
+
+    def _patch_and_co_attend(self, g_bag, bags: BagBatch, inference: bool):
+        n_slides, n_q, e = g_bag.shape
+        if not ops.fused_patch_coattn_supported(bags.data, e, n_q):
+            return super()._patch_and_co_attend(g_bag, bags, inference)
+        # row f1: ONE pass over the raw patch matrix (patch layer on the MFMA, co-attention while the tile is in LDS)
+        lin, co = self.H[0], self.co_attention
+        out, amap, _ = ops.patch_coattn_mcat(bags.data, bags, lin.weight, lin.bias, self.H[2].p if self.training else 0.0,
+                                             g_bag.reshape(n_slides * n_q, e), co.in_proj_weight, co.in_proj_bias,
+                                             co.out_proj.weight, co.out_proj.bias, inference)
+        return out.view(n_slides, n_q, e), (bags.split_map(amap, n_q) if inference else None)
 
     def forward(self, wsi, omics, inference: bool = False):
         return self._forward_one(wsi, omics, inference)

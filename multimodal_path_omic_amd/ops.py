@@ -370,6 +370,85 @@ def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk
     return out
 
 
+# ------------------------------------------------------------------------------------ row f1: patch layer + K1 in one pass
+class PatchCoAttnMCATFn(torch.autograd.Function):
+    """H_bag = dropout_p(relu(X W_H^T + b_H)) AND MCAT's co-attention over it (models/mcat/mcat.py:24-29,87,97) with ONE
+    pass over the raw bf16 patch matrix: mpo_patch_coattn_mcat_forward.  H_bag is written once (bf16) and kept for the
+    backward, which is K1's backward pass (d_bag arrives already multiplied by the ReLU / dropout derivative, with its
+    column sums = the patch layer's bias gradient) followed by the patch layer's weight gradient g^T X."""
+
+    @staticmethod
+    def forward(ctx, x, patch_w, patch_b, query, in_w, in_b, out_w, out_b, batch: BagBatch, need_weights: bool, drop_p: float):
+        lib = L.lib()
+        ctx.set_materialize_grads(False)
+        n_slides = batch.n_slides
+        R, E = query.shape
+        n_q = R // n_slides
+        dev, T = query.device, batch.total_rows
+        query = query.contiguous()
+        h_bag = torch.empty(T, E, device=dev, dtype=torch.bfloat16)
+        out = torch.empty(R, E, device=dev, dtype=torch.float32)
+        amap = torch.empty(n_q * T, device=dev, dtype=torch.float32) if need_weights else None
+        saved = torch.empty(lib.mpo_coattn_saved_floats(n_slides, n_q, E), device=dev, dtype=torch.float32)
+        ws = _workspace(lib.mpo_patch_coattn_workspace_bytes(n_slides, n_q, E, x.shape[1]), dev)
+        seed, off = _reserve(T * E // 16 + 2) if drop_p > 0 else (0, 0)
+        L.check(lib.mpo_patch_coattn_mcat_forward(
+            L.ptr(x), L.ptr(batch.cu), n_slides, T, batch.max_rows, x.shape[1], L.ptr(patch_w), L.ptr(patch_b), float(drop_p),
+            seed, off, _epoch(), L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), L.ptr(out_b),
+            L.ptr(h_bag), L.ptr(out), L.ptr(amap), L.ptr(saved), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)),
+            "mpo_patch_coattn_mcat_forward")
+        ctx.save_for_backward(x, h_bag, query, in_w, out_w, saved, amap)
+        ctx.param_refs = (patch_w, patch_b, in_w, in_b, out_w, out_b)
+        ctx.batch, ctx.n_q = batch, n_q
+        ctx.gate = 1.0 / (1.0 - _realised_drop(drop_p)) if drop_p > 0 else 1.0
+        ctx.mark_non_differentiable(h_bag)
+        return out, amap, h_bag
+
+    @staticmethod
+    def backward(ctx, d_out, d_map, _d_h):
+        lib = L.lib()
+        x, h_bag, query, in_w, out_w, saved, amap = ctx.saved_tensors
+        batch, n_q = ctx.batch, ctx.n_q
+        R, E = query.shape
+        dev = query.device
+        d_out = d_out.contiguous() if d_out is not None else torch.zeros(R, E, device=dev)
+        d_map = d_map.contiguous() if d_map is not None else None
+        d_query = torch.empty_like(query)
+        g = torch.empty_like(h_bag)               # d(pre-activation of the patch layer): ReLU/dropout derivative applied in-kernel
+        patch_w, patch_b, p_in_w, p_in_b, p_out_w, p_out_b = ctx.param_refs
+        d_pw, d_pb = grad_out(patch_w), grad_out(patch_b)
+        d_in_w, d_in_b, d_out_w, d_out_b = (grad_out(p) for p in (p_in_w, p_in_b, p_out_w, p_out_b))
+        ws = _workspace(lib.mpo_coattn_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows), dev)
+        L.check(lib.mpo_coattn_mcat_backward(
+            L.ptr(h_bag), L.MPO_BF16, L.ptr(batch.cu), batch.n_slides, batch.total_rows, batch.max_rows, L.ptr(query), n_q, E,
+            L.ptr(in_w), L.ptr(out_w), L.ptr(saved), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), L.ptr(g),
+            L.ptr(d_pb), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w), L.ptr(d_out_b), ctx.gate, batch.plan(), L.ptr(ws),
+            ws.numel(), L.stream_of(query)), "mpo_coattn_mcat_backward")
+        stats["colsum_handoffs"] += 1
+        if defer_patch_weight_grad and getattr(patch_w, "_mpo_grad_view", None) is not None \
+                and d_pw.data_ptr() == patch_w._mpo_grad_view.data_ptr():
+            _deferred_patch.append((g, x, d_pw))   # filled by flush_patch_weight_grads() (data-parallel split exchange)
+        else:
+            _splitk_tn(g, x, d_pw)
+        return None, d_pw, d_pb, d_query, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None
+
+
+def _realised_drop(p: float) -> float:
+    """The fused kernel draws 8 random bits per element: its drop probability is round(256 p) / 256."""
+    return float(int(p * 256.0 + 0.5)) / 256.0
+
+
+def patch_coattn_mcat(x_bf16, batch: BagBatch, patch_w, patch_b, drop_p: float, query, in_w, in_b, out_w, out_b,
+                      need_weights: bool):
+    """-> (out (n_slides*n_q, E), ragged map | None, H_bag (rows, E) bf16, not differentiable)."""
+    return PatchCoAttnMCATFn.apply(x_bf16, patch_w, patch_b, query, in_w, in_b, out_w, out_b, batch, need_weights, float(drop_p))
+
+
+def fused_patch_coattn_supported(x, embed: int, n_q: int) -> bool:
+    """mpo_patch_coattn_mcat_forward is built for a bf16 window, 1024 -> 256, at most 8 omic queries."""
+    return x.dtype == torch.bfloat16 and x.shape[1] == 1024 and embed == 256 and n_q <= 8
+
+
 def patch_fc(x_bf16, weight, bias, drop_p: float, pre_gated_grad: bool = False):
     h = PatchFcFn.apply(x_bf16, weight, bias, drop_p, pre_gated_grad)
     if pre_gated_grad:

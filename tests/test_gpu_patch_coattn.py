@@ -1,0 +1,204 @@
+"""Row f1: the patch layer fused with MCAT's co-attention forward (mpo_patch_coattn_mcat_forward, one pass over the raw
+patch matrix) against
+  * the CPU oracle fed the same stored values (bf16 patch matrix / weight operand / H_bag, fp32 arithmetic) -- the parity
+    check proper, incl. the reference's golden co-attention cases re-used as H-bag consumers;
+  * the unfused HIP path (library GEMM + epilogue kernel + K1), which it must reproduce up to the ONE rounding it removes
+    (the unfused path rounds the GEMM output to bf16 before the bias);
+  * itself on ragged windows (window == per-slide; block / tile / slide edges: 1, 31, 127, 128, 129, 257 ... rows);
+  * dropout: realised rate, keep scale, determinism per (seed, offset), fresh masks per epoch, backward mask consistency.
+Models reach this kernel through MultimodalCoAttentionTransformer with a bf16 bag (tests/test_gpu_models.py,
+test_gpu_graph.py, test_gpu_cohort.py, test_gpu_dp.py)."""
+import math
+
+import pytest
+import torch
+
+import cases as C
+from multimodal_path_omic_amd import ops
+from multimodal_path_omic_amd import synthetic as syn
+from multimodal_path_omic_amd.ops import BagBatch
+from oracle import mpo_oracle as O
+
+pytestmark = pytest.mark.gpu
+E, N_Q = 256, 6
+
+
+def _params(seed, gain=1.0):
+    shapes = {"H.0.weight": (E, 1024), "H.0.bias": (E,), **C.MCAT_COATTN_SHAPES}
+    return syn.fill_state_dict(shapes, seed, gain)
+
+
+def _inputs(lengths, seed):
+    g = syn.rng(seed)
+    bags = [syn.normal(g, (m, 1024)) for m in lengths]
+    query = syn.normal(g, (len(lengths) * N_Q, E))
+    return bags, query
+
+
+def _fused(p, bags, query, dev, need_weights=True, drop_p=0.0, n_q=N_Q):
+    batch = BagBatch.from_list([b.to(dev).to(torch.bfloat16) for b in bags])
+    d = {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
+    q = query.to(dev).requires_grad_(True)
+    out, amap, h = ops.patch_coattn_mcat(batch.data, batch, d["H.0.weight"], d["H.0.bias"], drop_p, q,
+                                         d["co_attention.in_proj_weight"], d["co_attention.in_proj_bias"],
+                                         d["co_attention.out_proj.weight"], d["co_attention.out_proj.bias"], need_weights)
+    return out, amap, h, d, q, batch
+
+
+def _unfused(p, bags, query, dev, need_weights=True):
+    batch = BagBatch.from_list([b.to(dev).to(torch.bfloat16) for b in bags])
+    d = {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
+    q = query.to(dev).requires_grad_(True)
+    h = ops.patch_fc(batch.data, d["H.0.weight"], d["H.0.bias"], 0.0, pre_gated_grad=True)
+    out, amap = ops.coattn_mcat(q, batch.with_data(h), d["co_attention.in_proj_weight"], d["co_attention.in_proj_bias"],
+                                d["co_attention.out_proj.weight"], d["co_attention.out_proj.bias"], need_weights, 1.0)
+    return out, amap, h, d, q, batch
+
+
+def _oracle(p, bag, query_rows):
+    """One slide through the oracle on the stored values the fused kernel sees: bf16 X and W_H operands, fp32 accumulate,
+    bias + ReLU in fp32, ONE rounding of H_bag to bf16; co-attention in fp32 on that H_bag."""
+    x = bag.bfloat16().float()
+    w = p["H.0.weight"].bfloat16().float()
+    h = torch.relu(x @ w.t() + p["H.0.bias"]).bfloat16().float()
+    out, a = O.mcat_coattention(query_rows, h, p)
+    return out, a, h
+
+
+def relmax(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("lengths,gain", [([256], 1.0), ([2000], 1.0), ([777], 2.0), ([15000], 1.0), ([2000], 4.0)],
+                         ids=["m256", "m2000", "m777_ragged", "m15000", "m2000_peaky"])
+def test_fused_forward_and_gradients_match_oracle(dev, lengths, gain):
+    p = _params(811, gain)
+    bags, query = _inputs(lengths, 812)
+    out, amap, h, d, q, batch = _fused(p, bags, query, dev)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    qr = query.clone().requires_grad_(True)
+    out_o, a_o, h_o = _oracle(pr, bags[0], qr)
+    # H_bag: the kernel accumulates in another order than the CPU GEMM: an element can land on the other side of a bf16
+    # rounding boundary (one ulp = 2^-8 relative), nothing more
+    hd = (h.float().cpu() - h_o.detach()).abs()
+    assert float((hd / h_o.detach().abs().clamp_min(1e-2)).max()) <= 2.0 ** -7
+    assert float((hd > 0).float().mean()) < 0.02
+    assert relmax(out.detach().cpu(), out_o.detach()) < 2e-3
+    a = amap.view(N_Q, lengths[0]).detach().cpu()
+    rel = float(((a - a_o.detach()).abs() / a_o.detach().clamp_min(1e-30)).max())
+    # the map sees the handful of one-ulp H differences above through |qk|: logits move by <= ~1e-3 at gain 1
+    assert rel < 3e-3 * gain, rel
+    probe_o, probe_a = syn.normal(syn.rng(5), (N_Q, E)), syn.normal(syn.rng(6), (N_Q, lengths[0]))
+    ((out * probe_o.to(dev)).sum() + (amap.view(N_Q, -1) * probe_a.to(dev)).sum()).backward()
+    ((out_o * probe_o).sum() + (a_o * probe_a).sum()).backward()
+    for k in p:
+        ref = pr[k].grad
+        tol = 2e-2 if k.startswith("H.") else 5e-3            # dH leaves K1's backward in bf16 on its way into dW_H
+        if k == "co_attention.in_proj_bias":
+            ref = ref.clone()
+            ref[E:2 * E] = 0                                    # the key bias cancels in the softmax (exactly zero here)
+        assert relmax(d[k].grad.cpu(), ref) < tol, (k, relmax(d[k].grad.cpu(), ref))
+    assert relmax(q.grad.cpu(), qr.grad) < 5e-3
+
+
+@pytest.mark.parametrize("lengths", [[1], [31, 32, 33], [127, 128, 129, 257, 1], [300, 1, 2048, 77], [5000] + [40] * 15 + [7] * 16],
+                         ids=["one_row", "tile_edges", "block_edges", "mixed", "one_giant_31_tiny"])
+def test_fused_equals_unfused_on_ragged_windows(dev, lengths):
+    p = _params(821)
+    bags, query = _inputs(lengths, 822)
+    out_f, map_f, h_f, d_f, q_f, batch = _fused(p, bags, query, dev)
+    out_u, map_u, h_u, d_u, q_u, _ = _unfused(p, bags, query, dev)
+    # the unfused path rounds the GEMM output to bf16 BEFORE the bias (two roundings), the fused one once
+    # (its pre-bias rounding moves an element by up to 2^-9 |x W^T|, i.e. < 0.02 absolute at these magnitudes, and can
+    # push an element across the ReLU kink)
+    hd = (h_f.float() - h_u.float()).abs().detach()
+    assert float(hd.max()) < 0.02 and float(hd.mean()) < 1e-3
+    assert relmax(out_f.detach(), out_u.detach()) < 5e-3
+    assert float(((map_f - map_u).abs() / map_u.clamp_min(1e-30)).max()) < 2e-2
+    # every row of every slide sums to one; slide b's block sits at n_q * cu[b]
+    off = 0
+    for m in lengths:
+        blk = map_f[N_Q * off:N_Q * (off + m)].view(N_Q, m)
+        torch.testing.assert_close(blk.sum(1), torch.ones(N_Q, device=dev), rtol=1e-4, atol=1e-4)
+        off += m
+    probe = syn.normal(syn.rng(7), tuple(out_f.shape)).to(dev)
+    (out_f * probe).sum().backward()
+    (out_u * probe).sum().backward()
+    for k in p:
+        assert relmax(d_f[k].grad, d_u[k].grad) < 2e-2, (k, relmax(d_f[k].grad, d_u[k].grad))
+    # window == slide by slide (same kernel, one-slide plans)
+    off = 0
+    for b, m in enumerate(lengths):
+        o1, m1, h1, *_ = _fused(p, [bags[b]], query[N_Q * b:N_Q * (b + 1)], dev)
+        assert relmax(o1.detach(), out_f.detach()[N_Q * b:N_Q * (b + 1)]) < 1e-4
+        assert torch.equal(h1, h_f[off:off + m])
+        off += m
+
+
+def test_fused_fewer_and_more_queries(dev):
+    """1 and 8 omic queries (the kernel's range); 9 and more fall back to the unfused path in the model."""
+    p = _params(831)
+    for n_q in (1, 8):
+        g = syn.rng(832 + n_q)
+        bag, query = syn.normal(g, (700, 1024)), syn.normal(g, (n_q, E))
+        out, amap, h, *_ = _fused(p, [bag], query, dev, n_q=n_q)
+        out_o, a_o, _ = _oracle(p, bag, query)
+        assert relmax(out.detach().cpu(), out_o) < 2e-3
+        assert float(((amap.view(n_q, 700).cpu() - a_o).abs() / a_o.clamp_min(1e-30)).max()) < 3e-3
+    assert not ops.fused_patch_coattn_supported(torch.empty(4, 1024, dtype=torch.bfloat16), 256, 9)
+    assert not ops.fused_patch_coattn_supported(torch.empty(4, 1024, dtype=torch.float32), 256, 6)
+
+
+def test_fused_dropout_masks(dev):
+    p = _params(841)
+    bags, query = _inputs([3000, 500], 842)
+    torch.manual_seed(1234)
+    ops.set_rng_epoch(None)
+    _, _, h0, *_ = _fused(p, bags, query, dev, need_weights=False, drop_p=0.0)
+    torch.manual_seed(1234)
+    calls = ops._rng_calls
+    out1, _, h1, d1, q1, _ = _fused(p, bags, query, dev, need_weights=False, drop_p=0.25)
+    ops._rng_calls = calls                                       # same (seed, offset) -> the same mask
+    _, _, h2, *_ = _fused(p, bags, query, dev, need_weights=False, drop_p=0.25)
+    assert torch.equal(h1, h2)
+    _, _, h3, *_ = _fused(p, bags, query, dev, need_weights=False, drop_p=0.25)      # next offset -> another mask
+    assert not torch.equal(h1, h3)
+    pos = h0 > 0
+    dropped = pos & (h1 == 0)
+    rate = float(dropped.sum()) / float(pos.sum())
+    assert abs(rate - 0.25) < 0.005, rate                        # ~4e5 positives: sigma ~ 7e-4
+    kept = pos & (h1 != 0)
+    ratio = (h1[kept].float() / h0[kept].float())
+    assert float((ratio - 4.0 / 3.0).abs().max()) < 0.02         # 1/(1-p) up to the bf16 rounding of both sides
+    # rows and columns are dropped independently (no stripe of a shared draw): per-column and per-row rates
+    col_rate = dropped.float().sum(0) / pos.float().sum(0).clamp_min(1)
+    assert float((col_rate - 0.25).abs().max()) < 0.06
+    # the epoch moves every stream
+    ep = torch.zeros(1, dtype=torch.int64, device=dev)
+    ops.set_rng_epoch(ep)
+    ops._rng_calls = calls
+    _, _, h4, *_ = _fused(p, bags, query, dev, need_weights=False, drop_p=0.25)
+    assert torch.equal(h4, h1)                                   # epoch 0 == no epoch
+    ep += 1
+    ops._rng_calls = calls
+    _, _, h5, *_ = _fused(p, bags, query, dev, need_weights=False, drop_p=0.25)
+    assert not torch.equal(h5, h1)
+    ops.set_rng_epoch(None)
+    # backward sees the same mask: d(sum out)/dW_H must equal the oracle's gradient with THIS mask replayed
+    out1.sum().backward()
+    keep = (h1 != 0).float().cpu() * (4.0 / 3.0)
+    keep[(h0 <= 0).cpu()] = 4.0 / 3.0                            # where relu is 0 the mask value is irrelevant
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    outs, off = [], 0
+    for b, bag in enumerate(bags):
+        m = bag.shape[0]
+        x = bag.bfloat16().float()
+        # (gradient flows to the fp32 master weight through the rounded operand as identity, like the kernel's)
+        h = torch.relu(x @ (pr["H.0.weight"] + (pr["H.0.weight"].bfloat16().float() - pr["H.0.weight"]).detach()).t()
+                       + pr["H.0.bias"]) * keep[off:off + m]
+        o, _ = O.mcat_coattention(query[N_Q * b:N_Q * (b + 1)], h, pr, need_weights=False)
+        outs.append(o)
+        off += m
+    torch.cat(outs).sum().backward()
+    assert relmax(d1["H.0.weight"].grad.cpu(), pr["H.0.weight"].grad) < 2e-2
+    assert relmax(d1["H.0.bias"].grad.cpu(), pr["H.0.bias"].grad) < 2e-2
