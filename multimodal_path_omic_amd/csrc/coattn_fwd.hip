@@ -35,12 +35,14 @@ struct FwdCfg {
 // at this tile's first row (row stride 1), written only for lanes with q < n_q.
 template <int E_, int NT>
 __device__ __forceinline__ void fwd_tile(const char* thi, const char* tlo, int nvalid,
-                                         const bf16x8 (&qh)[TileGeom<E_>::KS], const bf16x8 (&ql)[TileGeom<E_>::KS],
-                                         float& m_run, float& l_run, f32x4 (&acc)[TileGeom<E_>::DT],
+                                         const bf16x8 (&qh)[TileGeom<E_>::KS],
+                                         const bf16x8 (&qm)[E_ <= 256 ? TileGeom<E_>::KS : 1],
+                                         const bf16x8 (&ql)[TileGeom<E_>::KS], float& m_run, float& l_run, f32x4 (&acc)[TileGeom<E_>::DT],
                                          float* s_out, bool q_live, int lane) {
     const int g = lane >> 4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    tile_dot_rows<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);
+    if constexpr (E_ <= 256) tile_dot_rows3<E_, NT>(thi, tlo, qh, qm, ql, s0, s1, lane);
+    else tile_dot_rows<E_, NT>(thi, tlo, qh, ql, s0, s1, lane);       // ('big': the third term does not fit the register file)
     float sv[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -102,8 +104,9 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
     const int q = lane & 15;
     const bool q_live = q < n_q;
 
-    bf16x8 qh[G::KS], ql[G::KS];
-    load_query_frags<E_>(qk2 + (size_t)b * n_q * E_, n_q, lane, qh, ql);
+    bf16x8 qh[G::KS], qm[E_ <= 256 ? G::KS : 1], ql[G::KS];          // the score operand in three bf16 terms (coattn_tile.h)
+    if constexpr (E_ <= 256) load_query_frags3<E_>(qk2 + (size_t)b * n_q * E_, n_q, lane, qh, qm, ql);
+    else load_query_frags<E_>(qk2 + (size_t)b * n_q * E_, n_q, lane, qh, ql);
 
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 acc[G::DT];
@@ -160,7 +163,7 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
             asm volatile("" ::: "memory");                        // the tile's LDS reads stay below the wait
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            fwd_tile<E_, 1>(cur, cur, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
+            fwd_tile<E_, 1>(cur, cur, min(kTileRows, r1 - trow), qh, qm, ql, m_run, l_run, acc,
                             s_row ? s_row + trow : nullptr, q_live, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -177,7 +180,7 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
             if (it + 2 < n_my) sa.load(slide, trow + 2 * tstride, m_rows, 0, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            fwd_tile<E_, 1>(thi, tlo, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
+            fwd_tile<E_, 1>(thi, tlo, min(kTileRows, r1 - trow), qh, qm, ql, m_run, l_run, acc,
                             s_row ? s_row + trow : nullptr, q_live, lane);
             __builtin_amdgcn_wave_barrier();
             if (it + 1 < n_my) {
@@ -186,7 +189,7 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
                 if (it + 3 < n_my) sb.load(slide, trow + 2 * tstride, m_rows, 0, lane);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                fwd_tile<E_, 1>(thi, tlo, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
+                fwd_tile<E_, 1>(thi, tlo, min(kTileRows, r1 - trow), qh, qm, ql, m_run, l_run, acc,
                                 s_row ? s_row + trow : nullptr, q_live, lane);
                 __builtin_amdgcn_wave_barrier();
             }
@@ -207,7 +210,7 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            fwd_tile<E_, 2>(thi, tlo, min(kTileRows, r1 - trow), qh, ql, m_run, l_run, acc,
+            fwd_tile<E_, 2>(thi, tlo, min(kTileRows, r1 - trow), qh, qm, ql, m_run, l_run, acc,
                             s_row ? s_row + trow : nullptr, q_live, lane);
             __builtin_amdgcn_wave_barrier();
         }

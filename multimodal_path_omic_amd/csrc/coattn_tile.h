@@ -194,6 +194,58 @@ __device__ __forceinline__ void load_query_frags(const float* x /* [n_q][E] */, 
     }
 }
 
+// The same operand in THREE bf16 terms (hi + mid + lo = all 24 mantissa bits of x): for the score product of the forward
+// pass, where a logit of magnitude L moves the attention map by L x (operand error) relative -- two terms (2^-17) left a
+// peaky fixture (|logit| ~ 130) at 1.1e-3 on the map.
+template <int E_>
+__device__ __forceinline__ void load_query_frags3(const float* x /* [n_q][E] */, int n_q, int lane,
+                                                  bf16x8 (&hi)[TileGeom<E_>::KS], bf16x8 (&mid)[TileGeom<E_>::KS],
+                                                  bf16x8 (&lo)[TileGeom<E_>::KS]) {
+    const int q = lane & 15, g = lane >> 4;
+    const float live = q < n_q ? 1.0f : 0.0f;
+    const float* row = x + (q < n_q ? q : n_q - 1) * E_ + 8 * g;
+#pragma unroll
+    for (int s = 0; s < TileGeom<E_>::KS; ++s) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row + 32 * s);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(row + 32 * s + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (j < 4 ? a[j] : b[j - 4]) * live;
+            const __bf16 h = (__bf16)v;
+            const float r1 = v - (float)h;
+            const __bf16 m = (__bf16)r1;
+            hi[s][j] = h;
+            mid[s][j] = m;
+            lo[s][j] = (__bf16)(r1 - (float)m);
+        }
+    }
+}
+// scores^T with the three-term query operand; an fp32 bag (hi + lo images) adds lo x (hi + mid)
+template <int E_, int NT>
+__device__ __forceinline__ void tile_dot_rows3(const char* thi, const char* tlo, const bf16x8 (&xh)[TileGeom<E_>::KS],
+                                               const bf16x8 (&xm)[TileGeom<E_>::KS], const bf16x8 (&xl)[TileGeom<E_>::KS],
+                                               f32x4& s0, f32x4& s1, int lane) {
+#pragma unroll
+    for (int s = 0; s < TileGeom<E_>::KS; ++s) {
+        const bf16x8 a0 = row_frag<E_>(thi, 0, s, lane);
+        const bf16x8 a1 = row_frag<E_>(thi, 1, s, lane);
+        s0 = mfma_bf16(a0, xh[s], s0);
+        s1 = mfma_bf16(a1, xh[s], s1);
+        s0 = mfma_bf16(a0, xm[s], s0);
+        s1 = mfma_bf16(a1, xm[s], s1);
+        s0 = mfma_bf16(a0, xl[s], s0);
+        s1 = mfma_bf16(a1, xl[s], s1);
+        if (NT == 2) {
+            const bf16x8 b0 = row_frag<E_>(tlo, 0, s, lane);
+            const bf16x8 b1 = row_frag<E_>(tlo, 1, s, lane);
+            s0 = mfma_bf16(b0, xh[s], s0);
+            s1 = mfma_bf16(b1, xh[s], s1);
+            s0 = mfma_bf16(b0, xm[s], s0);
+            s1 = mfma_bf16(b1, xm[s], s1);
+        }
+    }
+}
+
 // scores^T for both 16-row halves of the tile:  s[pt][r] = sum_k tile[16pt + 4g + r][k] * x[q][k]
 template <int E_, int NT>
 __device__ __forceinline__ void tile_dot_rows(const char* thi, const char* tlo,

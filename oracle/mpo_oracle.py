@@ -51,13 +51,17 @@ def _store(t, dtype):
     return t if dtype is None else t.to(dtype).float()
 
 
-def patch_fc(wsi, p, prefix="H", keep=None, storage=None):
+def patch_fc(wsi, p, prefix="H", keep=None, storage=None, round_gemm_out=True):
     """H_bag = Drop(ReLU(X W_H^T + b)); models/mcat/mcat.py:24-29,87.
-    storage=torch.bfloat16 emulates the product's bf16 STORAGE points (patch matrix, GEMM weight operand,
-    GEMM output, H_bag) with fp32 arithmetic in between, so a bf16-stored run can be checked tightly."""
+    storage=torch.bfloat16 emulates the product's bf16 STORAGE points with fp32 arithmetic in between, so a bf16-stored
+    run can be checked tightly: patch matrix, GEMM weight operand, H_bag -- and, with round_gemm_out, the GEMM output
+    before the bias (the library-GEMM path of NaCAGaT; MCAT's fused patch-layer kernel keeps the accumulator in fp32 up
+    to the one rounding of H_bag)."""
     x = wsi.squeeze(0) if wsi.dim() == 3 else wsi
     x = _store(x.float(), storage)
-    h = _store(x @ _store(p[prefix + ".0.weight"], storage).t(), storage)
+    h = x @ _store(p[prefix + ".0.weight"], storage).t()
+    if round_gemm_out:
+        h = _store(h, storage)
     h = _store(torch.relu(h + p[prefix + ".0.bias"]), storage)
     return h if keep is None else h * keep
 
@@ -237,9 +241,10 @@ def _tail(h_coattn, g_bag, a_coattn, p, fusion="concat"):
     return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
 
 
-def mcat_forward(p, wsi, omics, inference=False, bag_storage=None, fusion="concat"):
-    """MultimodalCoAttentionTransformer.forward, models/mcat/mcat.py:84-142 (eval mode)."""
-    h_bag = patch_fc(wsi, p, storage=bag_storage)
+def mcat_forward(p, wsi, omics, inference=False, bag_storage=None, fusion="concat", round_gemm_out=False):
+    """MultimodalCoAttentionTransformer.forward, models/mcat/mcat.py:84-142 (eval mode).
+    bag_storage / round_gemm_out: see patch_fc (the fused kernel of the 'medium' model rounds H_bag once)."""
+    h_bag = patch_fc(wsi, p, storage=bag_storage, round_gemm_out=round_gemm_out)
     g_bag = omic_fc(omics, p)
     h_co, a_co = mcat_coattention(g_bag, h_bag, p, need_weights=inference)
     return _tail(h_co, g_bag, a_co, p, fusion)

@@ -82,10 +82,11 @@ def test_coattn_forward_backward(dev, golden, case, dtype):
     assert relerr(out1, out_o) < 1e-4
     # attention map: relative, element-wise
     rel_a = ((a1.detach().cpu() - a_o.detach()).abs() / a_o.detach().clamp_min(1e-30)).max().item()
-    # operands enter the MFMA as bf16 hi+lo pairs (2^-17 relative): a logit of magnitude L moves by ~8e-6 L and the
-    # map entry by the same RELATIVE amount.  The deliberately peaky fixture has |logit| ~ 130 -> ~1e-3 (the fp32
-    # oracle itself is 6e-5 from fp64 there); the others sit below 2e-4.
-    assert rel_a < (2e-3 if "peaky" in case else 1e-3), rel_a
+    # The score operand enters the MFMA in THREE bf16 terms (all 24 mantissa bits; two terms left the deliberately peaky
+    # fixture, |logit| ~ 130, at 1.1e-3): the north_star bar holds for every case (the fp32 oracle itself is 6e-5 from
+    # fp64 on the peaky one; an fp32 bag keeps a 2^-17 residual of its own hi + lo split).
+    print(f"[K1 map] {case} {str(dtype)[6:]}: rel err {rel_a:.2e}")
+    assert rel_a < 1e-3, rel_a
     torch.testing.assert_close(a1.sum(1).cpu(), torch.ones(C.N_OMIC), rtol=1e-4, atol=1e-4)
 
     params = dict(mod.named_parameters())
