@@ -170,7 +170,7 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
         plan = batch.plan()
         w = torch.randn(E, 1024, device=dev) / 32
         wb = torch.empty(E, 1024, device=dev, dtype=torch.bfloat16)
-        L.check(lib.mpo_cast_bf16(L.ptr(w), L.ptr(wb), w.numel(), stream.cuda_stream), "mpo_cast_bf16")
+        L.check(lib.mpo_pack_patch_weight(L.ptr(w), L.ptr(wb), E, 1024, stream.cuda_stream), "mpo_pack_patch_weight")
         bias = torch.randn(E, device=dev) * 0.1
         h_out = torch.empty(window * patches, E, device=dev, dtype=torch.bfloat16)
 

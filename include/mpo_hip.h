@@ -98,12 +98,13 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
                                   void* h_bag, float* out, float* attn_map /* nullable */, float* saved,
                                   const mpo_bag_plan* plan /* nullable */, void* workspace, size_t workspace_bytes,
                                   mpo_stream_t stream);
-/* The fused bag pass alone (measurement): w_bf16 [embed, patch_dim] bf16 from mpo_cast_bf16, qk2 [n_slides*n_q, embed]. */
-int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_bf16, const float* bias, const int32_t* cu_rows, int n_slides,
+/* The fused bag pass alone (measurement): w_packed = embed * patch_dim bf16 values from mpo_pack_patch_weight (the weight
+ * in the fragment order of the kernel's GEMM waves), qk2 [n_slides*n_q, embed]. */
+int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_packed, const float* bias, const int32_t* cu_rows, int n_slides,
                                  const float* qk2, void* h_bag, float* part_ml, float* part_ctx, int n_q, int max_rows,
                                  float drop_p, uint64_t seed, uint64_t offset, const mpo_bag_plan* plan /* nullable */,
                                  mpo_stream_t stream);
-int mpo_cast_bf16(const float* in, void* out, int64_t n /* multiple of 4 */, mpo_stream_t stream);
+int mpo_pack_patch_weight(const float* weight /* [embed, patch_dim] */, void* packed, int embed, int patch_dim, mpo_stream_t stream);
 
 /* d_attn_map (nullable): gradient arriving on the returned map; needs attn_map from the forward.
  * d_bag has the bag's dtype.  d_in_proj_bias[embed..2*embed) (the key bias) is exactly zero: a key

@@ -199,7 +199,7 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
     float* lse2 = attn + (size_t)R * E;
     const float scale = 1.0f / sqrtf((float)E);
     int rc;
-    if ((rc = mpo_launch_cast_bf16(patch_weight, w_bf16, (size_t)E * patch_dim, stream))) return rc;
+    if ((rc = mpo_launch_pack_patch_weight(patch_weight, w_bf16, E, patch_dim, stream))) return rc;
     if ((rc = mpo_linear_fwd(query, in_w, in_b, qs, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_linear_bwd_input(qs, in_w + (size_t)E * E, qk2, R, E, E, kLog2e, 0, stream))) return rc;
     if ((rc = mpo_launch_patch_coattn_fwd(patches, w_bf16, patch_bias, cu_rows, qk2, h_bag, part_ml, part_ctx, attn_map, n_q,
@@ -214,16 +214,16 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
 }
 
 // the fused bag pass alone (bench.py's roofline leg, profiling workloads)
-int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_bf16, const float* bias, const int32_t* cu_rows, int n_slides,
+int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_packed, const float* bias, const int32_t* cu_rows, int n_slides,
                                  const float* qk2, void* h_bag, float* part_ml, float* part_ctx, int n_q, int max_rows,
                                  float drop_p, uint64_t seed, uint64_t offset, const mpo_bag_plan* plan_, mpo_stream_t stream) {
     const BagPlan plan = make_plan(plan_, n_slides, max_rows);
     if (int rc = check_plan(plan, n_slides)) return rc;
-    return mpo_launch_patch_coattn_fwd(patches, w_bf16, bias, cu_rows, qk2, h_bag, part_ml, part_ctx, nullptr, n_q, drop_p, seed,
+    return mpo_launch_patch_coattn_fwd(patches, w_packed, bias, cu_rows, qk2, h_bag, part_ml, part_ctx, nullptr, n_q, drop_p, seed,
                                        offset, nullptr, plan, stream);
 }
-int mpo_cast_bf16(const float* in, void* out, int64_t n, mpo_stream_t stream) {
-    return mpo_launch_cast_bf16(in, out, (size_t)n, stream);
+int mpo_pack_patch_weight(const float* weight, void* packed, int embed, int patch_dim, mpo_stream_t stream) {
+    return mpo_launch_pack_patch_weight(weight, packed, embed, patch_dim, stream);
 }
 
 int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int total_rows,

@@ -139,7 +139,7 @@ inline int mpo_gemm_together(hipStream_t s, const GemmArgs& a, const GemmArgs& b
 struct BagPlan;
 extern "C" int mpo_coattn_splits(int n_slides, int max_rows);
 // row f1: patch layer + K1 forward in one pass over the raw patch matrix (patch_coattn_fwd.hip)
-int mpo_launch_cast_bf16(const float* in, void* out, size_t n, hipStream_t stream);
+int mpo_launch_pack_patch_weight(const float* w, void* out, int embed, int patch_dim, hipStream_t stream);
 int mpo_launch_patch_coattn_fwd(const void* x, const void* w_bf16, const float* bias, const int* cu, const float* qk2,
                                 void* h_out, float* part_ml, float* part_ctx, float* s_out, int n_q, float drop_p,
                                 unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,

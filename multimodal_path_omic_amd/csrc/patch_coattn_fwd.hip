@@ -191,7 +191,7 @@ __device__ __forceinline__ void copy_out_rows(const char* img, char* hrow, int r
 
 __global__ __launch_bounds__(NTHREADS, 3)
 void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows][1024] patch features
-                             const __bf16* __restrict__ wb,       // [256][1024] W_H rounded to bf16
+                             const __bf16* __restrict__ wb,       // W_H rounded to bf16, packed in fragment order (see load_w)
                              const float* __restrict__ bias,      // [256]
                              const int* __restrict__ cu,
                              const float* __restrict__ qk2,       // [n_slides][n_q][256], log2 units
@@ -246,14 +246,18 @@ void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows
         const int fc0 = ((0 + g) ^ fswz) << 4, fc1 = ((4 + g) ^ fswz) << 4;
         const uint32_t thr8 = (uint32_t)(drop_p * 256.0f + 0.5f); // keep iff byte >= thr8: realised p = thr8 / 256
         const float inv_keep = drop_p > 0.f ? 256.0f / (256.0f - (float)thr8) : 1.0f;
-        // W_H fragment of lane (i, g) for embed tile dt, k-half s of step k: 16 contiguous bytes of row 32 wave + 16 dt + i
-        const char* wrow = reinterpret_cast<const char*>(wb) + (size_t)(32 * wave + (lane & 15)) * (PK * 2) + 16 * g;
+        // W_H fragments come from a PACKED copy of the weight (pack_patch_weight_kernel below): the 64 fragments that one
+        // wave-instruction needs -- lane (i, g): row 32 wave + 16 dt + i, k = 64 step + 32 s + 8 g .. + 7 -- are 1 KiB
+        // contiguous, [wave][step][dt][s][lane][8].  Read in place from the row-major matrix the same instruction touches
+        // 16 rows x 64 B, which costs the address/texture path several times a contiguous KiB (measured: the GEMM waves
+        // then stalled at issue on their own weight loads).
+        const char* wpk = reinterpret_cast<const char*>(wb) + (size_t)wave * (KSTEPS * 4 * 1024) + lane * 16;
         auto load_w = [&](int k, bf16x8 (&w)[2][2]) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    w[dt][s] = *reinterpret_cast<const bf16x8*>(wrow + dt * 16 * (PK * 2) + k * SROWB + 64 * s);
+                    w[dt][s] = *reinterpret_cast<const bf16x8*>(wpk + ((k * 2 + dt) * 2 + s) * 1024);
         };
         int cslot = 0;
         f32x4 acc[2][8];
@@ -492,23 +496,30 @@ void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows
     }
 }
 
-__global__ void cast_f32_bf16_kernel(const f32x4* __restrict__ in, bf16x4* __restrict__ out, size_t n4) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const f32x4 v = in[i];
-    bf16x4 o;
+// W_H [256][1024] fp32 -> bf16 in the fragment order of the GEMM waves: block ((wave * 16 + step) * 2 + dt) * 2 + s of
+// 1 KiB holds, for lane (i = lane & 15, g = lane >> 4), W_H[32 wave + 16 dt + i][64 step + 32 s + 8 g .. + 7].
+__global__ void pack_patch_weight_kernel(const float* __restrict__ w, bf16x8* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte fragment per thread: 256 * 1024 / 8 of them
+    if (t >= PE * PK / 8) return;
+    const int lane = t & 63, blk = t >> 6;
+    const int s = blk & 1, dt = (blk >> 1) & 1, step = (blk >> 2) & (KSTEPS - 1), wave = blk >> 6;
+    const int row = 32 * wave + 16 * dt + (lane & 15), k0 = 64 * step + 32 * s + 8 * (lane >> 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)row * PK + k0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)row * PK + k0 + 4);
+    bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-    out[i] = o;
+    for (int j = 0; j < 4; ++j) {
+        o[j] = (__bf16)a[j];
+        o[4 + j] = (__bf16)b[j];
+    }
+    out[t] = o;
 }
 
 }  // namespace
 
-int mpo_launch_cast_bf16(const float* in, void* out, size_t n, hipStream_t stream) {
-    MPO_CHECK(n % 4 == 0, "cast: element count %zu is not a multiple of 4", n);
-    const size_t n4 = n / 4;
-    cast_f32_bf16_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(in),
-                                                                           reinterpret_cast<bf16x4*>(out), n4);
+int mpo_launch_pack_patch_weight(const float* w, void* out, int embed, int patch_dim, hipStream_t stream) {
+    MPO_CHECK(embed == PE && patch_dim == PK, "patch weight packing is built for %d x %d (got %d x %d)", PE, PK, embed, patch_dim);
+    pack_patch_weight_kernel<<<PE * PK / 8 / 256, 256, 0, stream>>>(w, reinterpret_cast<bf16x8*>(out));
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -21,7 +21,7 @@ plan = batch.plan()
 w = torch.randn(E, 1024, device=dev) / 32
 wb = torch.empty(E, 1024, device=dev, dtype=torch.bfloat16)
 stream = torch.cuda.current_stream(dev)
-L.check(lib.mpo_cast_bf16(L.ptr(w), L.ptr(wb), w.numel(), stream.cuda_stream), "cast")
+L.check(lib.mpo_pack_patch_weight(L.ptr(w), L.ptr(wb), E, 1024, stream.cuda_stream), "pack")
 bias = torch.randn(E, device=dev) * 0.1
 h_out = torch.empty(window * patches, E, device=dev, dtype=torch.bfloat16)
 parts = lib.mpo_coattn_target_workgroups() + window
