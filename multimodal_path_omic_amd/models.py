@@ -164,6 +164,11 @@ class NarrowContextualAttentionGateTransformer(_FusionModelBase):
 
     def __init__(self, omic_sizes: [], model_size: str = "medium", n_classes: int = 4, dropout: float = 0.25,
                  fusion: str = "concat", device: str = "cpu", bag_dtype: torch.dtype = torch.float32):
+        if model_size == "big":
+            # the reference accepts it (models/nacagat/nacagat.py:17-18); K2's bag kernels exist for d = 128 / 256 only:
+            # say so here instead of failing inside the first forward
+            raise NotImplementedError("NarrowContextualAttentionGateTransformer(model_size='big') (embed_dim 512) is not built: "
+                                      "the narrow-gated co-attention kernels cover 'small' and 'medium'")
         super().__init__(omic_sizes, model_size, n_classes, dropout, fusion, device, bag_dtype)
 
     def _make_co_attention(self, d):

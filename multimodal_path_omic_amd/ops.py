@@ -35,6 +35,11 @@ class BagBatch:
             target = L.lib().mpo_coattn_target_workgroups()
             rpw = -(-self.total_rows // target)
             rpw = max(32, -(-rpw // 32) * 32)
+            # every slide rounds its workgroup count up: grow the range until the WHOLE window fits one workgroup per CU
+            # (a window with more slides than CUs cannot).  A second, nearly empty round of workgroups costs a 50-us bag
+            # pass little, but doubles the 0.4-ms persistent patch-layer kernel (measured on the 2k-30k windows, r02).
+            while len(self.lengths) <= target and sum(-(-m // rpw) for m in self.lengths) > target:
+                rpw += 32
             starts = [0]
             for m in self.lengths:
                 starts.append(starts[-1] + -(-m // rpw))

@@ -99,3 +99,12 @@ def test_c_index_vectorised_equals_oracle_loop():
                 harness.concordance_index_censored(event, time, risk)
             continue
         assert harness.concordance_index_censored(event, time, risk) == pytest.approx(ref, abs=1e-12)
+
+
+def test_unbuilt_model_size_is_refused_at_construction():
+    from multimodal_path_omic_amd.models import (MultimodalCoAttentionTransformer,
+                                                 NarrowContextualAttentionGateTransformer)
+    with pytest.raises(NotImplementedError, match="big"):
+        NarrowContextualAttentionGateTransformer(omic_sizes=[8] * 6, model_size="big")
+    MultimodalCoAttentionTransformer(omic_sizes=[8] * 6, model_size="big")          # MCAT 'big' is built
+    NarrowContextualAttentionGateTransformer(omic_sizes=[8] * 6, model_size="small")
