@@ -115,7 +115,9 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
                              const float* in_proj_weight, const float* out_proj_weight,
                              const float* saved, const float* attn_map,
                              const float* d_out, const float* d_attn_map,
-                             float* d_query, void* d_bag, float* d_bag_colsum /* nullable [embed] */,
+                             float* d_query, int d_query_accumulate /* 1: d_query += (it arrives holding the gradient
+                                of the query's other use, e.g. as the omic branch's tokens) */,
+                             void* d_bag, float* d_bag_colsum /* nullable [embed] */,
                              float* d_in_proj_weight, float* d_in_proj_bias,
                              float* d_out_proj_weight, float* d_out_proj_bias,
                              float bag_relu_gate, const mpo_bag_plan* plan /* nullable */,
@@ -145,6 +147,10 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
                        float beta1, float beta2, float eps, float weight_decay, int step,
                        const int32_t* step_dev /* nullable: device-resident step count, overrides `step` */,
                        mpo_stream_t stream);
+
+/* rng_epoch += 1 and adam_step += 1 (either may be NULL) in one launch: the per-step device counters of a captured
+ * training step (dropout epoch of every mpo_*_forward, step count of mpo_adam_step_flat). */
+int mpo_step_counters_bump(uint64_t* rng_epoch, int32_t* adam_step, mpo_stream_t stream);
 
 /* ---- K2: NaCAGaT narrow-gated co-attention core = models/blocks.py:114-206 (heads = 1):
  *   S = (q/sqrt(E)) k^T * (tanh(q) tanh(k)^T + 1)/2,  A = softmax(S),  A_drop = dropout(A, p) in training,
@@ -283,6 +289,20 @@ int mpo_ces_loss_forward(const float* hazards, const float* survs, const int64_t
 int mpo_ces_loss_backward(const float* hazards, const float* survs, const int64_t* label, const float* censorship,
                           int n_slides, int n_classes, float alpha, float eps, const float* d_loss, int d_loss_is_scalar,
                           float* d_hazards, float* d_survs, mpo_stream_t stream);
+
+/* ---- training-step form of K6 + loss: ConcatFusion + classifier (models/fusion.py:17-19, mcat.py:126), then the survival
+ * head (mcat.py:130-138), the `ces` loss (models/loss.py:5-28) and the backward of both in ONE launch.  slide_weight
+ * (n_slides device floats) is the gradient the caller will send into the per-slide loss (1 / grad_acc_step in the
+ * reference's loop, models/mcat/main.py:69-70); mpo_fusion_head_loss_backward continues from the stored d_logits.
+ * Workspace of the backward: mpo_fusion_head_workspace_bytes. */
+size_t mpo_fusion_head_loss_saved_floats(int n_slides, int hidden, int dout, int n_classes);
+int mpo_fusion_head_loss_forward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
+                                 const float* const* params, const int64_t* label, const float* censorship,
+                                 const float* slide_weight, float alpha, float eps, float* hazards, float* survs, float* y,
+                                 float* loss, float* risk /* nullable */, float* saved, mpo_stream_t stream);
+int mpo_fusion_head_loss_backward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
+                                  const float* const* params, const float* saved, float* d_hcat, float* const* grads,
+                                  void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ---- K3: ContextualAttentionGate.forward (models/blocks.py:232-253) on rows of (Q, Q_hat).
  * 12 pointers: fc1.0.weight,.bias, fc2.0.weight,.bias, fc3.0.weight,.bias, G.1.weight,.bias, E.1.weight,.bias,

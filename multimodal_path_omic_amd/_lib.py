@@ -51,7 +51,7 @@ _SIGNATURES = {
                                              _P, _P]),
     "mpo_pack_patch_weight": (c_int, [_P, _P, c_int, c_int, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
-                                         _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
+                                         _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
     "mpo_colsum_bf16": (c_int, [_P, _P, ctypes.c_int64, c_int, _P]),
     "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     "mpo_patch_epilogue_forward": (c_int, [_P, _P, ctypes.c_int64, c_int, c_float, c_uint64, c_uint64, _P, _P]),
@@ -83,6 +83,10 @@ _SIGNATURES = {
     "mpo_fusion_head_workspace_bytes": (c_size_t, [c_int] * 4),
     "mpo_fusion_head_forward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P, _P, _P]),
     "mpo_fusion_head_backward": (c_int, [_P] + [c_int] * 5 + [_P] * 10 + [_P, c_size_t, _P]),
+    "mpo_fusion_head_loss_saved_floats": (c_size_t, [c_int] * 4),
+    "mpo_fusion_head_loss_forward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P, c_float, c_float] + [_P] * 6 + [_P]),
+    "mpo_fusion_head_loss_backward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P] + [_P, c_size_t, _P]),
+    "mpo_step_counters_bump": (c_int, [_P, _P, _P]),
     "mpo_omic_snn_saved_floats": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_workspace_bytes": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_rng_span": (c_uint64, [c_int] * 3),

@@ -391,74 +391,150 @@ __device__ __forceinline__ void tanh_frag(bf16x8 xh, bf16x8 xl, bf16x8& th, bf16
     pack_hi_lo(t, th, tl);
 }
 
-// (i') ONE pass over K:  a_map[n][m] = K[m] . r1[n]   and   g_map[n][m] = tanh(K[m]) . r2[n]
-template <int E_, bool F32BAG>
-__global__ __launch_bounds__((BagCfg<E_, F32BAG>::WAVES * 64), 1)
-void bag_rowdot_gated_kernel(const void* __restrict__ bag_, const int* __restrict__ cu, const float* __restrict__ r1,
-                             const float* __restrict__ r2, float* __restrict__ a_map, float* __restrict__ g_map,
-                             int n_q, BagPlan plan) {
-    using G = TileGeom<E_>;
-    using C = BagCfg<E_, F32BAG>;
-    constexpr int NT = C::NT;
+// (i') ONE pass over an fp32 K:  a_map[n][m] = K[m] . r1[n]   and   g_map[n][m] = tanh(K[m]) . r2[n],
+// exact: both products on the fp32-input MFMA, no operand splitting, so
+// a_map / g_map carry plain fp32 rounding and the peaky-softmax parity bar of 1e-3 holds with margin.
+// With N = 6 queries the 16x16x4 shape would idle 10 of its 16 columns (measured: 158.9 us, MFMA-bound);
+// v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4x1 blocks, 8 cycles) keeps 6 of 8:
+//   block b = lane/4 takes A from lanes 4b..4b+3 and B from its own lanes: D[lane][r] = A[4(lane/4)+r] * B[lane]
+//   (lane mapping checked on the card by tools/probe_mfma4x4.hip).
+// A wave owns a 16-row fp32 tile (raw rows, stride E*4 + 16 bytes: conflict-free ds_read_b128); lane
+// (row = l%16, phase = l/16) contracts k = 16u + 4*phase + j at step (u, j), so one b128 read of the row feeds four
+// steps, and the four phases are summed by two lane exchanges at the end of the tile.  B operands come from two
+// per-slide LDS tables [k/4][column 0..7][4] (16-byte entries, broadcast reads): qs and -2*tq, with
+// tanh(x) = 1 - 2r, r = 1/(2^(2x log2 e) + 1) folded as g = sum(tq) - 2 sum(r tq).  Eight waves per CU, tiles staged
+// through registers (NOTES.md r02-K2: the direct-to-LDS form with 8-row tiles has half the bytes in flight and is slower).
+template <int E_>
+struct GateCfg {
+    static constexpr int WAVES = 8;
+    static constexpr int ROWS = 16;
+    static constexpr int ROWB = E_ * 4 + 16;
+    static constexpr int TILEB = ROWS * ROWB;
+    static constexpr int TAB = (E_ / 4) * 8 * 16;
+    static constexpr int OFF_TAB = WAVES * TILEB;
+    static constexpr int OFF_SUM = OFF_TAB + 2 * TAB;
+    static constexpr int LDS_BYTES = OFF_SUM + 64;           // E = 256: 149 568 bytes
+    static constexpr int CH = E_ / 4;                        // 16-byte chunks per row
+    static constexpr int NLD = ROWS * CH / 64;               // global loads per lane per tile
+    static constexpr int KU = E_ / 16;
+};
+
+template <int E_>
+struct GateStage {
+    using C = GateCfg<E_>;
+    f32x4 v[C::NLD];
+    __device__ __forceinline__ void load(const char* slide, int row0, int m_rows, int lane) {
+#pragma unroll
+        for (int i = 0; i < C::NLD; ++i) {
+            const int ci = i * 64 + lane;
+            int grow = row0 + ci / C::CH;
+            grow = grow < m_rows ? grow : m_rows - 1;
+            v[i] = *reinterpret_cast<const f32x4*>(slide + ((size_t)grow * C::CH + ci % C::CH) * 16);
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int lane) const {
+#pragma unroll
+        for (int i = 0; i < C::NLD; ++i) {
+            const int ci = i * 64 + lane;
+            *reinterpret_cast<f32x4*>(tile + (ci / C::CH) * C::ROWB + (ci % C::CH) * 16) = v[i];
+        }
+    }
+};
+
+__device__ __forceinline__ f32x4 mfma_4x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 sum_phases(f32x4 v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] += __shfl_xor(v[r], 16, 64);
+        v[r] += __shfl_xor(v[r], 32, 64);
+    }
+    return v;
+}
+__device__ __forceinline__ float pick(f32x4 v, int p) {
+    return p == 0 ? v[0] : p == 1 ? v[1] : p == 2 ? v[2] : v[3];
+}
+
+template <int E_>
+__global__ __launch_bounds__(GateCfg<E_>::WAVES * 64, 1)
+void bag_rowdot_gated_exact_kernel(const float* __restrict__ bag, const int* __restrict__ cu,
+                                   const float* __restrict__ r1, const float* __restrict__ r2,
+                                   float* __restrict__ a_map, float* __restrict__ g_map, int n_q, BagPlan plan) {
+    using C = GateCfg<E_>;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const SplitGeom sg = split_geom<C::WAVES>(cu, plan, wave);
-    const int b = sg.b;
-    char* thi = lds + wave * C::WAVE_LDS;
-    char* tlo = thi + (NT - 1) * G::TILEB;
-    const int q = lane & 15, g = lane >> 4;
-    bf16x8 ah[G::KS], al[G::KS], gh[G::KS], gl[G::KS];
-    load_query_frags<E_>(r1 + (size_t)b * n_q * E_, n_q, lane, ah, al);
-    load_query_frags<E_>(r2 + (size_t)b * n_q * E_, n_q, lane, gh, gl);
-    const size_t mbase = (size_t)n_q * sg.row_begin + (size_t)q * sg.m_rows;
-    const char* slide = reinterpret_cast<const char*>(bag_) + (size_t)sg.row_begin * E_ * (F32BAG ? 4 : 2);
-    Stage<E_, F32BAG> st0, st1;
-    if (sg.n_my > 0) {
-        st0.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 0, lane);
-        if constexpr (F32BAG) st1.load(slide, sg.r0 + kTileRows * wave, sg.m_rows, 1, lane);
-    }
-    for (int it = 0; it < sg.n_my; ++it) {
-        const int trow = sg.r0 + kTileRows * (wave + it * C::WAVES);
-        const int nvalid = min(kTileRows, sg.r1 - trow);
-        st0.store(thi, tlo, 0, lane);
-        if constexpr (F32BAG) st1.store(thi, tlo, 1, lane);
-        if (it + 1 < sg.n_my) {
-            st0.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 0, lane);
-            if constexpr (F32BAG) st1.load(slide, trow + kTileRows * C::WAVES, sg.m_rows, 1, lane);
+    const SplitGeom sg = split_geom<4>(cu, plan, wave >> 1);          // a wave pair shares the plan's 32-row tiles
+    char* tile = lds + wave * C::TILEB;
+    // operand tables of this slide: entry (k4, col) = r[col][4 k4 .. +3], zero for col >= n_q
+    for (int idx = threadIdx.x; idx < (E_ / 4) * 8; idx += C::WAVES * 64) {
+        const int k4 = idx >> 3, col = idx & 7;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vg = va;
+        if (col < n_q) {
+            va = *reinterpret_cast<const f32x4*>(r1 + ((size_t)sg.b * n_q + col) * E_ + 4 * k4);
+            vg = *reinterpret_cast<const f32x4*>(r2 + ((size_t)sg.b * n_q + col) * E_ + 4 * k4) * -2.0f;
         }
+        *reinterpret_cast<f32x4*>(lds + C::OFF_TAB + idx * 16) = va;
+        *reinterpret_cast<f32x4*>(lds + C::OFF_TAB + C::TAB + idx * 16) = vg;
+    }
+    if (wave == 0) {                                                   // sum_e tq[col][e]: eight lanes per column
+        const int col = lane >> 3, part = lane & 7;
+        float acc = 0.f;
+        if (col < n_q)
+            for (int e = part; e < E_; e += 8) acc += r2[((size_t)sg.b * n_q + col) * E_ + e];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (part == 0) reinterpret_cast<float*>(lds + C::OFF_SUM)[col] = acc;
+    }
+    __syncthreads();
+    const int row = lane & 15, ph = lane >> 4;
+    const char* arow = tile + row * C::ROWB + 16 * ph;
+    const char* btab = lds + C::OFF_TAB + (ph * 8 + (lane & 3)) * 16;
+    const char* slide = reinterpret_cast<const char*>(bag) + (size_t)sg.row_begin * E_ * 4;
+    const int half = C::ROWS * (wave & 1);
+    const int orow = 4 * ((lane >> 2) & 3) + ph;                       // the output row this lane stores
+    const int c0 = lane & 3, c1 = 4 + (lane & 3);
+    const float st0 = reinterpret_cast<const float*>(lds + C::OFF_SUM)[c0];
+    const float st1 = reinterpret_cast<const float*>(lds + C::OFF_SUM)[c1];
+    float* am = a_map + (size_t)n_q * sg.row_begin;
+    float* gm = g_map + (size_t)n_q * sg.row_begin;
+    GateStage<E_> st;
+    if (sg.n_my > 0) st.load(slide, sg.r0 + kTileRows * (wave >> 1) + half, sg.m_rows, lane);
+    for (int it = 0; it < sg.n_my; ++it) {
+        const int trow = sg.r0 + kTileRows * ((wave >> 1) + it * 4) + half;
+        const int nvalid = min(C::ROWS, sg.r1 - trow);                 // may be <= 0 for the upper half of a last tile
+        st.store(tile, lane);
+        if (it + 1 < sg.n_my) st.load(slide, trow + kTileRows * 4, sg.m_rows, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, g0 = a0, g1 = a0;
 #pragma unroll
-        for (int s = 0; s < G::KS; ++s) {
+        for (int u = 0; u < C::KU; ++u) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(arow + 64 * u);
+            const f32x4 qa0 = *reinterpret_cast<const f32x4*>(btab + 512 * u);
+            const f32x4 qa1 = *reinterpret_cast<const f32x4*>(btab + 512 * u + 64);
+            const f32x4 qg0 = *reinterpret_cast<const f32x4*>(btab + C::TAB + 512 * u);
+            const f32x4 qg1 = *reinterpret_cast<const f32x4*>(btab + C::TAB + 512 * u + 64);
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                const bf16x8 xh = row_frag<E_>(thi, pt, s, lane);
-                const bf16x8 xl = NT == 2 ? row_frag<E_>(tlo, pt, s, lane) : xh;
-                f32x4& a = pt == 0 ? a0 : a1;
-                f32x4& gg = pt == 0 ? g0 : g1;
-                a = mfma_bf16(xh, ah[s], a);
-                a = mfma_bf16(xh, al[s], a);
-                if (NT == 2) a = mfma_bf16(xl, ah[s], a);
-                bf16x8 th, tl;
-                tanh_frag<NT>(xh, xl, th, tl);
-                gg = mfma_bf16(th, gh[s], gg);
-                gg = mfma_bf16(th, gl[s], gg);
-                gg = mfma_bf16(tl, gh[s], gg);
+            for (int j = 0; j < 4; ++j) {
+                const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[j] * (2.0f * kLog2e)) + 1.0f);
+                a0 = mfma_4x4(x[j], qa0[j], a0);
+                a1 = mfma_4x4(x[j], qa1[j], a1);
+                g0 = mfma_4x4(r, qg0[j], g0);
+                g1 = mfma_4x4(r, qg1[j], g1);
             }
         }
-        if (q < n_q) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                if (4 * g + rr < nvalid) {
-                    a_map[mbase + trow + 4 * g + rr] = a0[rr];
-                    g_map[mbase + trow + 4 * g + rr] = g0[rr];
-                }
-                if (16 + 4 * g + rr < nvalid) {
-                    a_map[mbase + trow + 16 + 4 * g + rr] = a1[rr];
-                    g_map[mbase + trow + 16 + 4 * g + rr] = g1[rr];
-                }
+        a0 = sum_phases(a0); a1 = sum_phases(a1); g0 = sum_phases(g0); g1 = sum_phases(g1);
+        if (orow < nvalid) {
+            if (c0 < n_q) {
+                am[(size_t)c0 * sg.m_rows + trow + orow] = pick(a0, ph);
+                gm[(size_t)c0 * sg.m_rows + trow + orow] = pick(g0, ph) + st0;
+            }
+            if (c1 < n_q) {
+                am[(size_t)c1 * sg.m_rows + trow + orow] = pick(a1, ph);
+                gm[(size_t)c1 * sg.m_rows + trow + orow] = pick(g1, ph) + st1;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1183,11 +1259,8 @@ int mpo_launch_bag_rowdot_gated(const void* bag, int bag_f32, const int* cu, int
                                 const float* r2, float* a_map, float* g_map, int n_q, const BagPlan& plan, hipStream_t stream) {
     (void)n_slides;
     dim3 grid = plan_grid(plan);
-    if (bag_f32) {
-        MPO_E_SWITCH(embed, (bag_rowdot_gated_kernel<EV, true><<<grid, BagCfg<EV, true>::WAVES * 64, 0, stream>>>(bag, cu, r1, r2, a_map, g_map, n_q, plan)))
-    } else {
-        MPO_E_SWITCH(embed, (bag_rowdot_gated_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, r1, r2, a_map, g_map, n_q, plan)))
-    }
+    MPO_CHECK(bag_f32, "bag_rowdot_gated: the key bag is fp32 (K2 projects bf16 bags into fp32 keys first)");
+    MPO_E_SWITCH(embed, (bag_rowdot_gated_exact_kernel<EV><<<grid, GateCfg<EV>::WAVES * 64, 0, stream>>>(static_cast<const float*>(bag), cu, r1, r2, a_map, g_map, n_q, plan)))
     MPO_LAUNCH_CHECK();
     return 0;
 }

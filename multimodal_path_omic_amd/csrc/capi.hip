@@ -79,7 +79,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 8; }
+int mpo_abi_version(void) { return 9; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -229,7 +229,8 @@ int mpo_pack_patch_weight(const float* weight, void* packed, int embed, int patc
 int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int total_rows,
                              int max_rows, const float* query, int n_q, int embed, const float* in_w,
                              const float* out_w, const float* saved, const float* attn_map, const float* d_out,
-                             const float* d_attn_map, float* d_query, void* d_bag, float* d_bag_colsum, float* d_in_w,
+                             const float* d_attn_map, float* d_query, int d_query_accumulate, void* d_bag,
+                             float* d_bag_colsum, float* d_in_w,
                              float* d_in_b, float* d_out_w, float* d_out_b, float bag_relu_gate, const mpo_bag_plan* plan_,
                              void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
@@ -264,22 +265,27 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
     if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dattn, w_v, dctx, R, E, E, 1.0f, 0),
                                   mpo_args_bwd_weight(dattn, ctx, d_in_w + (size_t)2 * E * E, d_in_b + 2 * E, R, E, E, 1.0f),
                                   stream))) return rc;
-    // delta = rowsum(dctx * ctx) [+ rowsum(A * dA_ext)]
-    if ((rc = mpo_launch_rowdot(dctx, ctx, delta, R, E, stream))) return rc;
-    if (d_attn_map)
+    // delta = rowsum(dctx * ctx) [+ rowsum(A * dA_ext)]: inside the bag pass unless a map gradient adds its term
+    if (d_attn_map) {
+        if ((rc = mpo_launch_rowdot(dctx, ctx, delta, R, E, stream))) return rc;
         if ((rc = mpo_launch_map_rowdot(attn_map, d_attn_map, cu_rows, delta, n_slides, n_q, 1, stream))) return rc;
+    }
     // the bag pass
-    if ((rc = mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, E, qk2, lse2, dctx, delta, attn_map,
-                                    d_attn_map, d_bag, part_dqk, part_cs, n_q, plan, bag_relu_gate, stream))) return rc;
-    if ((rc = mpo_launch_coattn_bwd_reduce(part_dqk, dqk, n_slides, n_q, E, plan, stream))) return rc;
-    if (d_bag_colsum)
-        if ((rc = mpo_launch_colsum(part_cs, d_bag_colsum, (int)plan_parts(plan), E, E, 0, stream))) return rc;
-    // qk = qs W_k :  dqs = dqk W_k^T (folded with the 1/sqrt(E) of qs = scale * (...)),  dW_k = qs^T dqk,  db_k = 0
+    if ((rc = mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, E, qk2, lse2, dctx,
+                                    d_attn_map ? delta : nullptr, ctx, attn_map, d_attn_map, d_bag, part_dqk, part_cs, n_q,
+                                    plan, bag_relu_gate, stream))) return rc;
+    {   // one launch: dqk = sum of the split-M partials, the bag's column sums, db_k = 0 (softmax is shift-invariant)
+        BagFinish f{};
+        f.part[0] = part_dqk; f.out[0] = dqk; f.n_red = 1;
+        f.part_cs = part_cs; f.colsum = d_bag_colsum; f.cs_cols = E;
+        f.zero[0] = d_in_b + E; f.n_zero[0] = E;
+        if ((rc = mpo_launch_bag_finish(f, n_slides, n_q, E, plan, stream))) return rc;
+    }
+    // qk = qs W_k :  dqs = dqk W_k^T (folded with the 1/sqrt(E) of qs = scale * (...)),  dW_k = qs^T dqk
     if ((rc = mpo_gemm_together(stream, mpo_args_fwd(dqk, w_k, nullptr, dq_pre, R, E, E, scale, MPO_ACT_NONE),
                                 mpo_args_bwd_weight(qs, dqk, d_in_w + (size_t)E * E, nullptr, R, E, E, 1.0f)))) return rc;
-    MPO_HIP(hipMemsetAsync(d_in_b + E, 0, (size_t)E * sizeof(float), stream));
     // q_pre = query W_q^T + b_q
-    if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dq_pre, w_q, d_query, R, E, E, 1.0f, 0),
+    if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dq_pre, w_q, d_query, R, E, E, 1.0f, d_query_accumulate ? 1 : 0),
                                   mpo_args_bwd_weight(dq_pre, query, d_in_w, d_in_b, R, E, E, 1.0f), stream))) return rc;
     return 0;
 }
@@ -413,8 +419,11 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     // query side: dq~ = ds1 K, dtq = dg TK
     // (one pass over K, tanh on the fly)
     if ((rc = mpo_launch_bag_colacc_gated(kbag, 1, cu_rows, n_slides, E, ds1_map, dg_map, part, part2, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_coattn_bwd_reduce(part, dqt, n_slides, n_q, E, splits, stream))) return rc;
-    if ((rc = mpo_launch_coattn_bwd_reduce(part2, dtq, n_slides, n_q, E, splits, stream))) return rc;
+    {
+        BagFinish f{};
+        f.part[0] = part; f.out[0] = dqt; f.part[1] = part2; f.out[1] = dtq; f.n_red = 2;
+        if ((rc = mpo_launch_bag_finish(f, n_slides, n_q, E, splits, stream))) return rc;
+    }
     if ((rc = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
     if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0),
                                   mpo_args_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f), stream))) return rc;
@@ -422,14 +431,16 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     // (one pass: tanh' from the staged K tile)
     if ((rc = mpo_launch_bag_outer_gated(static_cast<const float*>(kbag), cu_rows, n_slides, E, ds1_map, qt, dg_map, tq,
                                          d_kbag, dk_dtype == MPO_F32, part_cs, n_q, splits, stream))) return rc;
-    if (d_kbag_colsum)
-        if ((rc = mpo_launch_colsum(part_cs, d_kbag_colsum, (int)plan_parts(splits), E, E, 0, stream))) return rc;
+    {   // one launch: the key bag's column sums, and zeros for the key slice of the packed in-projection (it belongs to
+        // the caller's K = H W_k^T + b_k; a caller may have the key-bias gradient written straight into its slice)
+        BagFinish f{};
+        f.part_cs = d_kbag_colsum ? part_cs : nullptr; f.colsum = d_kbag_colsum; f.cs_cols = E;
+        f.zero[0] = d_in_w + (size_t)E * E; f.n_zero[0] = E * E;
+        if (d_kbag_colsum != d_in_b + E) { f.zero[1] = d_in_b + E; f.n_zero[1] = E; }
+        if ((rc = mpo_launch_bag_finish(f, n_slides, n_q, E, splits, stream))) return rc;
+    }
     if (d_ctx == nullptr)
         if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, attn_map, dctx, nullptr, nullptr, d_hbag, f32, n_q, splits, stream))) return rc;
-    // the key slice of the packed in-projection belongs to the caller's K = H W_k^T + b_k
-    MPO_HIP(hipMemsetAsync(d_in_w + (size_t)E * E, 0, (size_t)E * E * sizeof(float), stream));
-    if (d_kbag_colsum != d_in_b + E)            // (a caller may have the key-bias gradient written straight into its slice)
-        MPO_HIP(hipMemsetAsync(d_in_b + E, 0, (size_t)E * sizeof(float), stream));
     return 0;
 }
 
@@ -491,7 +502,8 @@ int mpo_coattn_bwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_row
                            const mpo_bag_plan* plan_, mpo_stream_t stream) {
     const BagPlan plan = make_plan(plan_, n_slides, max_rows);
     if (int rc = check_plan(plan, n_slides)) return rc;
-    return mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, lse2, dctx, delta, nullptr,
+    MPO_CHECK(delta, "coattn backward bag pass: delta is required here");
+    return mpo_launch_coattn_bwd(bag, bag_dtype == MPO_F32, cu_rows, n_slides, embed, qk2, lse2, dctx, delta, nullptr, nullptr,
                                  d_attn_map, d_bag, part_dqk, nullptr, n_q, plan, 0.f, stream);
 }
 
@@ -524,6 +536,12 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
     MPO_CHECK(step >= 1 || step_dev, "adam: step counts from 1 (got %d)", step);
     return mpo_launch_adam_flat(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay,
                                 step < 1 ? 1 : step, step_dev, stream);
+}
+
+// The two device-resident per-step counters of a captured training step, bumped by one launch.
+int mpo_step_counters_bump(uint64_t* rng_epoch, int32_t* adam_step, mpo_stream_t stream) {
+    MPO_CHECK(rng_epoch || adam_step, "step counters: nothing to bump");
+    return mpo_launch_counters_bump(reinterpret_cast<unsigned long long*>(rng_epoch), adam_step, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

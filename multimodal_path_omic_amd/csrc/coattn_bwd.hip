@@ -65,7 +65,8 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
                        const float* __restrict__ qk2,      // [n_slides][n_q][E] log2 units
                        const float* __restrict__ lse2,     // [n_slides][n_q]    log2 units
                        const float* __restrict__ dctx,     // [n_slides][n_q][E]
-                       const float* __restrict__ delta,    // [n_slides][n_q]
+                       const float* __restrict__ delta,    // [n_slides][n_q] = rowsum(dctx * ctx) (+ map term); NULL: computed here from ctx
+                       const float* __restrict__ ctx,      // [n_slides][n_q][E], read when delta == NULL
                        const float* __restrict__ da_map,   // nullable, ragged [n_q][M_b] per slide
                        void* __restrict__ dbag_,           // [total_rows][E], bag dtype
                        float* __restrict__ part_dqk,       // [n_slides][splits][n_q][E] (natural units)
@@ -119,14 +120,35 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
 
     // per-lane row constants in both orientations; +inf lse switches padded query rows off (A = 0)
     const float lse_q = c16 < n_q ? lse2[(size_t)b * n_q + c16] : INFINITY;
-    const float del_q = c16 < n_q ? delta[(size_t)b * n_q + c16] : 0.f;
-    float lse_p[4], del_p[4];
+    float del_q, lse_p[4], del_p[4];
+    if (delta != nullptr) {
+        del_q = c16 < n_q ? delta[(size_t)b * n_q + c16] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qq = 4 * g + r;
-        lse_p[r] = qq < n_q ? lse2[(size_t)b * n_q + qq] : INFINITY;
-        del_p[r] = qq < n_q ? delta[(size_t)b * n_q + qq] : 0.f;
+        for (int r = 0; r < 4; ++r) del_p[r] = 4 * g + r < n_q ? delta[(size_t)b * n_q + 4 * g + r] : 0.f;
+    } else {
+        // delta[q] = dctx[q] . ctx[q]: lane (q = c16, g) sums a quarter of the row, every wave on its own (no exchange
+        // through LDS; this used to be a launch of its own in front of the bag pass)
+        const float* cx_b = ctx + (size_t)b * n_q * E_;
+        float acc = 0.f;
+        if (c16 < n_q) {
+#pragma unroll 4
+            for (int e = g * (E_ / 4); e < (g + 1) * (E_ / 4); e += 4) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(dc_b + c16 * E_ + e);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cx_b + c16 * E_ + e);
+                acc += (u[0] * v[0] + u[1] * v[1]) + (u[2] * v[2] + u[3] * v[3]);
+            }
+        }
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        del_q = c16 < n_q ? acc : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = __shfl(acc, 4 * g + r, 64);               // lane q of the wave holds row q's total
+            del_p[r] = 4 * g + r < n_q ? t : 0.f;
+        }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lse_p[r] = 4 * g + r < n_q ? lse2[(size_t)b * n_q + 4 * g + r] : INFINITY;
     const float* da_b = da_map ? da_map + (size_t)n_q * row_begin : nullptr;
 
     f32x4 accq[G::DT];
@@ -396,26 +418,45 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
     }
 }
 
-// dqk[b][i] = sum_s part[b][s][i]: 64 float4 columns per workgroup, the 4 waves split the splits
+// The small work that follows a split-M bag pass, in ONE launch (each used to be its own 4.7 us graph node):
+//   rows y < n_slides * n_red : out_k[b][i] = sum_s part_k[s][i] over slide b's workgroups (64 float4 columns per
+//                               workgroup, the 4 waves split the partials);
+//   the extra row y == n_slides * n_red : column sums over ALL partials (colsum[c] = sum_s part_cs[s][c], the bias
+//                               gradient of the layer that produced the bag) and zero-fills of up to two regions.
 __global__ __launch_bounds__(256)
-void coattn_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int per_slide, BagPlan plan) {
+void bag_finish_kernel(BagFinish f, int n_slides, int per_slide, BagPlan plan) {
     __shared__ __attribute__((aligned(16))) float red[4][256];
-    const int b = blockIdx.y, c = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i4 = blockIdx.x * 64 + c;                       // float4 index inside the slide's block
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i4 = blockIdx.x * 64 + c;                       // float4 index inside the row's block
+    const int rows_red = n_slides * f.n_red;
+    const bool extra = (int)blockIdx.y >= rows_red;
+    if (extra) {
+        const int tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (f.zero[k])
+                for (int i = tid; i < f.n_zero[k]; i += nthr) f.zero[k][i] = 0.f;
+        if (f.part_cs == nullptr || 4 * (int)blockIdx.x * 64 >= f.cs_cols) return;
+    }
+    const int which = extra ? 0 : (int)blockIdx.y / n_slides, b = extra ? 0 : (int)blockIdx.y % n_slides;
+    const float* part = extra ? f.part_cs : f.part[which];
+    float* out = extra ? f.colsum : f.out[which] + (size_t)b * per_slide;
+    const int width = extra ? f.cs_cols : per_slide;
     int s0, s1;
-    slide_parts(plan, b, s0, s1);
+    if (extra) { s0 = 0; s1 = (int)plan_parts_dev(plan); }
+    else slide_parts(plan, b, s0, s1);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (4 * i4 < per_slide)
+    if (4 * i4 < width)
         for (int s = s0 + w; s < s1; s += 4)
-            a += *reinterpret_cast<const f32x4*>(part + (size_t)s * per_slide + 4 * i4);
+            a += *reinterpret_cast<const f32x4*>(part + (size_t)s * width + 4 * i4);
     *reinterpret_cast<f32x4*>(&red[w][4 * c]) = a;
     __syncthreads();
-    if (w == 0 && 4 * i4 < per_slide) {
+    if (w == 0 && 4 * i4 < width) {
         f32x4 t = *reinterpret_cast<const f32x4*>(&red[0][4 * c]);
         t += *reinterpret_cast<const f32x4*>(&red[1][4 * c]);
         t += *reinterpret_cast<const f32x4*>(&red[2][4 * c]);
         t += *reinterpret_cast<const f32x4*>(&red[3][4 * c]);
-        *reinterpret_cast<f32x4*>(out + (size_t)b * per_slide + 4 * i4) = t;
+        *reinterpret_cast<f32x4*>(out + 4 * i4) = t;
     }
 }
 
@@ -469,22 +510,23 @@ int mpo_launch_map_block_scale(const float* a_map, const float* scale, const int
 }
 
 int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
-                          const float* qk2, const float* lse2, const float* dctx, const float* delta,
+                          const float* qk2, const float* lse2, const float* dctx, const float* delta, const float* ctx,
                           const float* a_map, const float* da_map,
                           void* dbag, float* part_dqk, float* part_colsum, int n_q, const BagPlan& plan, float relu_gate,
                           hipStream_t stream) {
     (void)n_slides;
     (void)a_map;
     MPO_CHECK(relu_gate == 0.f || !bag_f32, "coattn backward: the fused relu/dropout gate needs a bf16 bag");
+    MPO_CHECK(delta || ctx, "coattn backward: delta or ctx");
     dim3 grid = plan_grid(plan);
 #define MPO_BWD_CASE(EV)                                                                                     \
     case EV:                                                                                                 \
         if (bag_f32)                                                                                         \
             coattn_bwd_kernel<EV, true><<<grid, BwdCfg<EV, true>::WAVES * 64, 0, stream>>>(                  \
-                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, part_colsum, n_q, plan, relu_gate);  \
+                bag, cu, qk2, lse2, dctx, delta, ctx, da_map, dbag, part_dqk, part_colsum, n_q, plan, relu_gate);  \
         else                                                                                                 \
             coattn_bwd_kernel<EV, false><<<grid, BwdCfg<EV, false>::WAVES * 64, 0, stream>>>(                \
-                bag, cu, qk2, lse2, dctx, delta, da_map, dbag, part_dqk, part_colsum, n_q, plan, relu_gate);  \
+                bag, cu, qk2, lse2, dctx, delta, ctx, da_map, dbag, part_dqk, part_colsum, n_q, plan, relu_gate);  \
         break;
     switch (embed) {
         MPO_BWD_CASE(128)
@@ -499,13 +541,23 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
     return 0;
 }
 
-int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, const BagPlan& plan,
-                                 hipStream_t stream) {
+int mpo_launch_bag_finish(const BagFinish& f, int n_slides, int n_q, int embed, const BagPlan& plan, hipStream_t stream) {
+    MPO_CHECK(f.n_red >= 0 && f.n_red <= 2, "bag finish: 0..2 reductions (got %d)", f.n_red);
+    MPO_CHECK((embed & 3) == 0 && (f.cs_cols & 3) == 0, "bag finish: widths must be multiples of 4");
     const int per = n_q * embed;
-    dim3 grid((per / 4 + 63) / 64, n_slides);
-    coattn_bwd_reduce_kernel<<<grid, 256, 0, stream>>>(part_dqk, dqk, per, plan);
+    int bx = f.n_red ? (per / 4 + 63) / 64 : 1;
+    if (f.part_cs) bx = max(bx, (f.cs_cols / 4 + 63) / 64);
+    if (f.zero[0] || f.zero[1]) bx = max(bx, 8);
+    dim3 grid(bx, n_slides * f.n_red + 1);
+    bag_finish_kernel<<<grid, 256, 0, stream>>>(f, n_slides, per, plan);
     MPO_LAUNCH_CHECK();
     return 0;
+}
+int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, const BagPlan& plan,
+                                 hipStream_t stream) {
+    BagFinish f{};
+    f.part[0] = part_dqk; f.out[0] = dqk; f.n_red = 1;
+    return mpo_launch_bag_finish(f, n_slides, n_q, embed, plan, stream);
 }
 
 int mpo_launch_rowdot(const float* a, const float* b, float* out, int rows, int cols, hipStream_t stream) {

@@ -42,6 +42,7 @@ struct BagPlan {
 };
 inline dim3 plan_grid(const BagPlan& p) { return p.wg_start ? dim3(p.n_wg, 1) : dim3(p.splits, p.n_slides); }
 inline size_t plan_parts(const BagPlan& p) { return p.wg_start ? (size_t)p.n_wg : (size_t)p.splits * p.n_slides; }
+__device__ __forceinline__ size_t plan_parts_dev(const BagPlan& p) { return p.wg_start ? (size_t)p.n_wg : (size_t)p.splits * p.n_slides; }
 
 struct WgGeom {
     int b, row_begin, m_rows, r0, r1, ntiles;

@@ -152,10 +152,23 @@ int mpo_launch_coattn_combine(const float* part_ml, const float* part_ctx, float
 int mpo_launch_coattn_normalize(float* a, const float* lse2, const int* cu, int n_slides, int n_q, int max_rows,
                                 float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream);
 int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
-                          const float* qk2, const float* lse2, const float* dctx, const float* delta,
-                          const float* a_map, const float* da_map,
+                          const float* qk2, const float* lse2, const float* dctx, const float* delta /* NULL: from ctx */,
+                          const float* ctx, const float* a_map, const float* da_map,
                           void* dbag, float* part_dqk, float* part_colsum /* nullable [parts][E] */, int n_q, const BagPlan& plan,
                           float relu_gate, hipStream_t stream);
+// what follows a split-M bag pass, one launch: up to two per-slide reductions of [parts][n_q*E] partials, the column
+// sums over all partials of a [parts][cs_cols] array, zero-fills of up to two regions (coattn_bwd.hip: bag_finish_kernel)
+struct BagFinish {
+    const float* part[2];
+    float* out[2];
+    int n_red;
+    const float* part_cs;
+    float* colsum;
+    int cs_cols;
+    float* zero[2];
+    int n_zero[2];
+};
+int mpo_launch_bag_finish(const BagFinish& f, int n_slides, int n_q, int embed, const BagPlan& plan, hipStream_t stream);
 int mpo_launch_coattn_bwd_reduce(const float* part_dqk, float* dqk, int n_slides, int n_q, int embed, const BagPlan& plan,
                                  hipStream_t stream);
 int mpo_launch_rowdot(const float* a, const float* b, float* out, int rows, int cols, hipStream_t stream);
@@ -214,6 +227,10 @@ int mpo_launch_pool_fwd(const float* scores, const float* x, float* w, float* h,
 int mpo_launch_pool_bwd(const float* dh, const float* x, const float* w, const float* d_ext, float* d_scores, float* dx,
                         int B, int L, int d, hipStream_t s);
 int mpo_launch_head_fwd(const float* logits, float* hazards, float* survs, float* y, int B, int C, hipStream_t s);
+int mpo_launch_head_loss(const float* logits, const long long* label, const float* cens, const float* w, float* hazards,
+                         float* survs, float* y, float* loss, float* risk, float* dlogits, int B, int C, float alpha,
+                         float eps, hipStream_t s);
+int mpo_launch_counters_bump(unsigned long long* epoch, int* step, hipStream_t s);
 int mpo_launch_head_bwd(const float* hazards, const float* survs, const float* y, const float* dhz, const float* dsv,
                         const float* dy, float* dlogits, int B, int C, hipStream_t s);
 int mpo_launch_ew_mul(const float* a, const float* b, float* out, int n, hipStream_t s);

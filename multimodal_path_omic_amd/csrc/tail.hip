@@ -364,6 +364,63 @@ __global__ void ces_loss_bwd_kernel(const float* __restrict__ hazards, const flo
     if (sy >= eps) d_survs[o + y] += -(1.0f - alpha) * g * (c / sy - (1.0f - c) / (1.0f - sy));
 }
 
+// Training step: survival head, 'ces' loss and BOTH their backward passes for a slide, one thread, one launch: the
+// loss's upstream gradient w[b] is known before the forward in a training step (1 / grad_acc_step per slide), and four
+// dependent 4.7 us graph nodes (head, loss, d loss, d head) are one.  Same arithmetic as the four kernels above.
+__global__ void head_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                 const float* __restrict__ cens, const float* __restrict__ w,
+                                 float* __restrict__ hazards, float* __restrict__ survs, float* __restrict__ y,
+                                 float* __restrict__ loss, float* __restrict__ risk, float* __restrict__ dlogits,
+                                 int B, int C, float alpha, float eps) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t o = (size_t)b * C;
+    float hz[kMaxC], sv[kMaxC];
+    float mx = logits[o];
+    for (int j = 1; j < C; ++j) mx = fmaxf(mx, logits[o + j]);
+    float s = 0.f, run = 1.0f, r = 0.f;
+    for (int j = 0; j < C; ++j) s += __expf(logits[o + j] - mx);
+    for (int j = 0; j < C; ++j) {
+        hz[j] = 1.0f / (1.0f + __expf(-logits[o + j]));
+        run *= 1.0f - hz[j];
+        sv[j] = run;
+        r -= run;
+        hazards[o + j] = hz[j];
+        survs[o + j] = run;
+        y[o + j] = __expf(logits[o + j] - mx) / s;
+    }
+    const int yb = (int)label[b];
+    const float c = cens[b];
+    const float s_prev = yb == 0 ? 1.0f : sv[yb - 1];
+    const float reg = -(1.0f - c) * (logf(fmaxf(s_prev, eps)) + logf(fmaxf(hz[yb], eps)));
+    const float sy = fmaxf(sv[yb], eps);
+    const float ce = -(c * logf(sy) + (1.0f - c) * logf(1.0f - sy));
+    loss[b] = (1.0f - alpha) * ce + alpha * reg;
+    if (risk) risk[b] = r;
+    // d loss / d (hazards, survs), then through cumprod and sigmoid (head_bwd_kernel with dy = 0)
+    const float g = w[b];
+    float tail = 0.f;
+    float dl[kMaxC];
+    for (int i = C - 1; i >= 0; --i) {
+        float dsv = 0.f, dh = 0.f;
+        if (i == yb) {
+            if (hz[i] >= eps) dh = -alpha * (1.0f - c) * g / hz[i];
+            if (sv[i] >= eps) dsv += -(1.0f - alpha) * g * (c / sv[i] - (1.0f - c) / (1.0f - sv[i]));
+        }
+        if (i == yb - 1 && sv[i] >= eps) dsv += -alpha * (1.0f - c) * g / sv[i];
+        tail += dsv * sv[i];
+        dh -= tail / fmaxf(1.0f - hz[i], 1e-30f);
+        dl[i] = dh * hz[i] * (1.0f - hz[i]);
+    }
+    for (int i = 0; i < C; ++i) dlogits[o + i] = dl[i];
+}
+__global__ void counters_bump_kernel(unsigned long long* __restrict__ epoch, int* __restrict__ step) {
+    if (threadIdx.x == 0) {
+        if (epoch) epoch[0] += 1ull;
+        if (step) step[0] += 1;
+    }
+}
+
 // ------------------------------------------------------------------ element-wise helpers
 __global__ void ew_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -539,6 +596,19 @@ int mpo_launch_ces_loss_bwd(const float* hazards, const float* survs, const long
     MPO_CHECK(B >= 1 && C >= 1, "ces loss: empty batch (%d x %d)", B, C);
     ces_loss_bwd_kernel<<<(B + 63) / 64, 64, 0, s>>>(hazards, survs, label, cens, d_loss, d_loss_scalar, d_hazards, d_survs,
                                                      B, C, alpha, eps);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_head_loss(const float* logits, const long long* label, const float* cens, const float* w, float* hazards,
+                         float* survs, float* y, float* loss, float* risk, float* dlogits, int B, int C, float alpha,
+                         float eps, hipStream_t s) {
+    MPO_CHECK(B >= 1 && C >= 1 && C <= kMaxC, "head + ces loss: %d slides x %d classes (classes in 1..%d)", B, C, kMaxC);
+    head_loss_kernel<<<(B + 63) / 64, 64, 0, s>>>(logits, label, cens, w, hazards, survs, y, loss, risk, dlogits, B, C, alpha, eps);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_counters_bump(unsigned long long* epoch, int* step, hipStream_t s) {
+    counters_bump_kernel<<<1, 64, 0, s>>>(epoch, step);
     MPO_LAUNCH_CHECK();
     return 0;
 }

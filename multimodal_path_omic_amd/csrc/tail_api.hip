@@ -405,6 +405,52 @@ int mpo_fusion_head_backward(const float* hcat, int n_slides, int din, int hidde
     return 0;
 }
 
+// Training-step form: the same MLP, then head + 'ces' loss + their backward in ONE launch (head_loss_kernel); the
+// gradient w.r.t. the logits is kept in `saved` and the backward starts at the classifier products.
+// saved: z1 [B,hidden] | z2 [B,dout] | logits [B,C] | d_logits [B,C]
+size_t mpo_fusion_head_loss_saved_floats(int n_slides, int hidden, int dout, int n_classes) {
+    CarveSizer c;
+    c.take((size_t)n_slides * hidden); c.take((size_t)n_slides * dout); c.take((size_t)n_slides * n_classes);
+    c.take((size_t)n_slides * n_classes);
+    return c.n;
+}
+int mpo_fusion_head_loss_forward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
+                                 const float* const* P, const int64_t* label, const float* censorship,
+                                 const float* slide_weight, float alpha, float eps, float* hazards, float* survs, float* y,
+                                 float* loss, float* risk, float* saved, mpo_stream_t stream) {
+    MPO_CHECK(hcat && P && label && censorship && slide_weight && hazards && survs && y && loss && saved,
+              "fusion head + loss forward: null argument");
+    Carver c(saved);
+    float* z1 = c.take((size_t)n_slides * hidden); float* z2 = c.take((size_t)n_slides * dout);
+    float* logits = c.take((size_t)n_slides * n_classes); float* dlogits = c.take((size_t)n_slides * n_classes);
+    RC(mpo_linear_fwd(hcat, P[0], P[1], z1, n_slides, din, hidden, 1.0f, MPO_ACT_RELU, stream));
+    RC(mpo_linear_fwd(z1, P[2], P[3], z2, n_slides, hidden, dout, 1.0f, MPO_ACT_RELU, stream));
+    RC(mpo_linear_fwd(z2, P[4], P[5], logits, n_slides, dout, n_classes, 1.0f, MPO_ACT_NONE, stream));
+    RC(mpo_launch_head_loss(logits, reinterpret_cast<const long long*>(label), censorship, slide_weight, hazards, survs, y,
+                            loss, risk, dlogits, n_slides, n_classes, alpha, eps, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+int mpo_fusion_head_loss_backward(const float* hcat, int n_slides, int din, int hidden, int dout, int n_classes,
+                                  const float* const* P, const float* saved, float* d_hcat, float* const* G,
+                                  void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    Carver c(const_cast<float*>(saved));
+    const float* z1 = c.take((size_t)n_slides * hidden); const float* z2 = c.take((size_t)n_slides * dout);
+    c.take((size_t)n_slides * n_classes);
+    const float* dlogits = c.take((size_t)n_slides * n_classes);
+    Arena ws(workspace, workspace_bytes);
+    ws.floats((size_t)n_slides * n_classes);                    // (layout of mpo_fusion_head_workspace_bytes)
+    float* dz2 = ws.floats((size_t)n_slides * dout);
+    float* dz1 = ws.floats((size_t)n_slides * hidden);
+    MPO_CHECK(dz2 && dz1, "fusion head + loss backward: workspace too small (%zu bytes)", workspace_bytes);
+    PAIR(mpo_args_bwd_input(dlogits, P[4], dz2, n_slides, dout, n_classes, 1.0f, 0),
+         mpo_args_bwd_weight(dlogits, z2, G[4], G[5], n_slides, dout, n_classes, 1.0f));
+    PAIR(mpo_args_bwd_input(dz2, P[2], dz1, n_slides, hidden, dout, 1.0f, 0, gate(z2, MPO_GATE_RELU)),
+         mpo_args_bwd_weight(dz2, z1, G[2], G[3], n_slides, hidden, dout, 1.0f, gate(z2, MPO_GATE_RELU)));
+    PAIR(mpo_args_bwd_input(dz1, P[0], d_hcat, n_slides, din, hidden, 1.0f, 0, gate(z1, MPO_GATE_RELU)),
+         mpo_args_bwd_weight(dz1, hcat, G[0], G[1], n_slides, din, hidden, 1.0f, gate(z1, MPO_GATE_RELU)));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- survival head alone
 // hazards = sigmoid(logits), survs = cumprod(1 - hazards), Y = softmax(logits)   (models/mcat/mcat.py:130-138)
 int mpo_survival_head_forward(const float* logits, int n_slides, int n_classes, float* hazards, float* survs, float* y,

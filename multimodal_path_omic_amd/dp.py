@@ -110,11 +110,13 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)   # step count, device-resident
 
-    def step(self):
+    def step(self, bump: bool = True):
         """One update.  The step count is incremented and read on the device, so the call can sit inside a
-        captured HIP graph and still apply the right bias correction on every replay."""
+        captured HIP graph and still apply the right bias correction on every replay.  bump=False: the caller has
+        advanced t_dev already (ops.bump_step_counters, one launch for it and the dropout epoch)."""
         from . import _lib as L
-        self.t_dev += 1
+        if bump:
+            self.t_dev += 1
         b = self.bucket
         L.check(L.lib().mpo_adam_step_flat(L.ptr(self.flat_p), L.ptr(b.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                            self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,

@@ -76,6 +76,13 @@ def train_window(model, bags: BagBatch, omics, labels, cens, grad_acc_step: int,
         per_slide, risk = ops.ces_loss(hazards, survs, labels, cens)
         per_slide = per_slide + lambda_reg * ops.map_block_norm(att["coattn"])
     elif loss == "ces":
+        if getattr(model, "fusion", None) == "concat":
+            # head, loss and the backward of both in one launch: the loss gradient is known before the forward
+            w = _slide_weights(bags.n_slides, grad_acc_step, labels.device)
+            _, _, _, att = model.forward_window(bags, omics, ces_targets=(labels, cens, w))
+            per_slide, risk = att["loss"], att["risk"]
+            per_slide.backward(w)
+            return per_slide.detach(), risk
         hazards, survs, _, _ = model.forward_window(bags, omics)
         per_slide, risk = ops.ces_loss(hazards, survs, labels, cens)              # one HIP launch each way
     else:
@@ -152,7 +159,7 @@ class GraphedWindowStep:
 
     def _body(self, flush: bool = True):
         from . import ops
-        self.epoch += 1
+        ops.bump_step_counters(self.epoch, self.opt.t_dev if self.opt is not None else None)   # one launch for both
         self.bucket.begin()
         bags, omics, labels, cens = self.window
         ops.defer_patch_weight_grad = self.split
@@ -164,7 +171,7 @@ class GraphedWindowStep:
         if self.split and flush:
             ops.flush_patch_weight_grads()
         if self.opt is not None:
-            self.opt.step()
+            self.opt.step(bump=False)
         return out
 
     def head_numel(self) -> int:

@@ -75,30 +75,48 @@ class _FusionModelBase(nn.Module):
             h = F.dropout(torch.relu(F.linear(x.float(), lin.weight, lin.bias)), p, self.training)
         return bags.with_data(h)
 
-    def _patch_and_co_attend(self, g_bag, bags: BagBatch, inference: bool):
-        """Patch layer + co-attention (models/mcat/mcat.py:87,97).  Subclasses with a fused kernel override this."""
-        return self._co_attend(g_bag, self._patch_fc(bags), inference)
+    def _token_pair(self, bags: BagBatch, omics):
+        return None
 
-    def _omic_fc(self, omics: "List[torch.Tensor]") -> torch.Tensor:
+    def _patch_and_co_attend(self, g_bag, bags: BagBatch, inference: bool, pair=None):
+        """Patch layer + co-attention (models/mcat/mcat.py:87,97) -> (co-attended tokens, map, the omic tokens to hand to
+        the omic branch).  Subclasses with a fused kernel override this."""
+        h, a = self._co_attend(g_bag, self._patch_fc(bags), inference)
+        return h, a, g_bag
+
+    def _omic_fc(self, omics: "List[torch.Tensor]", tokens=None) -> torch.Tensor:
         """omics: per group a (B, d_i) tensor -> G_bag (B, N, d)."""
-        return ops.omic_snn(omics, self.G, self.training)
+        return ops.omic_snn(omics, self.G, self.training, tokens)
 
     # ---- window API
-    def forward_window(self, bags: BagBatch, omics: "List[torch.Tensor]", inference: bool = False):
+    def forward_window(self, bags: BagBatch, omics: "List[torch.Tensor]", inference: bool = False, ces_targets=None):
         """bags: raw patch features (total_rows, 1024) of the window; omics: per group (B, d_i).
         Returns hazards, survs, Y (B, C) and {'coattn': [ (N, M_b) ] | None, 'path': (B,1,N), 'omic': (B,1,N)}.
+        ces_targets = (labels, censorship, slide_weight) (training step, fusion 'concat'): the `ces` loss and its backward
+        ride in the head's launch (ops.fusion_head_loss_cat); the dict gains 'loss' and 'risk' (per slide), and
+        backward must be driven as loss.backward(slide_weight).
 
         The path and the omic set-Transformer / pooling head have identical geometry and run as ONE launch sequence
         with grouped GEMMs (ops.encoder_stacked, ops.gated_pool_stacked): the token tail is a latency-bound chain of
         small launches, so the omic branch rides along in launches the path branch needs anyway."""
-        g_bag = self._omic_fc(omics)
-        h_coattn, a_coattn = self._patch_and_co_attend(g_bag, bags, inference)
-        tokens = ops.encoder_stacked(torch.stack([h_coattn, g_bag]),
-                                     [list(self.path_transformer.layers), list(self.omic_transformer.layers)], self.training)
+        pair = self._token_pair(bags, omics)
+        g_bag = self._omic_fc(omics, pair)
+        h_coattn, a_coattn, g_tok = self._patch_and_co_attend(g_bag, bags, inference, pair)
+        stacked = pair.stack(h_coattn, g_tok) if pair is not None else torch.stack([h_coattn, g_tok])
+        tokens = ops.encoder_stacked(stacked, [list(self.path_transformer.layers), list(self.omic_transformer.layers)],
+                                     self.training)
         a, h = ops.gated_pool_stacked(tokens, [self.path_attention_head, self.omic_attention_head],
                                       [self.path_rho, self.omic_rho], self.training)
+        att = {"coattn": a_coattn, "path": a[0], "omic": a[1]}
+        if ces_targets is not None:
+            if self.fusion != "concat":
+                raise ValueError("forward_window(ces_targets=...) is built for fusion 'concat'")
+            hcat = h.transpose(0, 1).reshape(h.shape[1], -1)
+            att["loss"], att["risk"], hazards, survs, y = ops.fusion_head_loss_cat(hcat, self.fusion_layer, self.classifier,
+                                                                                   *ces_targets)
+            return hazards, survs, y, att
         hazards, survs, y = self._fuse_and_head(h[0], h[1], h)
-        return hazards, survs, y, {"coattn": a_coattn, "path": a[0], "omic": a[1]}
+        return hazards, survs, y, att
 
     def _fuse_and_head(self, h_path, h_omic, stacked=None):
         """Fusion + classifier + survival head (models/mcat/mcat.py:119-138).  `concat` is one K6 call; the other fusion
@@ -144,16 +162,24 @@ class MultimodalCoAttentionTransformer(_FusionModelBase):
             gate = 1.0 / (1.0 - self.H[2].p) if self.training else 1.0
         return self.co_attention.forward_window(g_bag, h_bags, need_weights=inference, bag_relu_gate=gate)
 
-    def _patch_and_co_attend(self, g_bag, bags: BagBatch, inference: bool):
-        n_slides, n_q, e = g_bag.shape
+    def _token_pair(self, bags: BagBatch, omics):
+        """Row f1 writes the co-attention output and the omic tokens straight into the (2, B, N, d) buffer the
+        branch-batched encoder reads (no torch.stack copy, no gradient add for the doubly-used G_bag)."""
+        n_q, e = len(omics), self.H[0].out_features
         if not ops.fused_patch_coattn_supported(bags.data, e, n_q):
+            return None
+        return ops.TokenPair(bags.n_slides * n_q, e, bags.data.device)
+
+    def _patch_and_co_attend(self, g_bag, bags: BagBatch, inference: bool, pair=None):
+        n_slides, n_q, e = g_bag.shape
+        if pair is None:
             return super()._patch_and_co_attend(g_bag, bags, inference)
         # row f1: ONE pass over the raw patch matrix (patch layer on the MFMA, co-attention while the tile is in LDS)
         lin, co = self.H[0], self.co_attention
-        out, amap, _ = ops.patch_coattn_mcat(bags.data, bags, lin.weight, lin.bias, self.H[2].p if self.training else 0.0,
-                                             g_bag.reshape(n_slides * n_q, e), co.in_proj_weight, co.in_proj_bias,
-                                             co.out_proj.weight, co.out_proj.bias, inference)
-        return out.view(n_slides, n_q, e), (bags.split_map(amap, n_q) if inference else None)
+        out, amap, _, g_tok = ops.patch_coattn_mcat(bags.data, bags, lin.weight, lin.bias, self.H[2].p if self.training else 0.0,
+                                                    g_bag.reshape(n_slides * n_q, e), co.in_proj_weight, co.in_proj_bias,
+                                                    co.out_proj.weight, co.out_proj.bias, inference, pair)
+        return out.view(n_slides, n_q, e), (bags.split_map(amap, n_q) if inference else None), g_tok.view(n_slides, n_q, e)
 
     def forward(self, wsi, omics, inference: bool = False):
         return self._forward_one(wsi, omics, inference)

@@ -237,7 +237,7 @@ class CoAttnMCATFn(torch.autograd.Function):
         L.check(lib.mpo_coattn_mcat_backward(
             L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, batch.total_rows,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(out_w), L.ptr(saved), L.ptr(amap),
-            L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), L.ptr(d_bag), L.ptr(colsum), L.ptr(d_in_w), L.ptr(d_in_b),
+            L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), 0, L.ptr(d_bag), L.ptr(colsum), L.ptr(d_in_w), L.ptr(d_in_b),
             L.ptr(d_out_w), L.ptr(d_out_b), ctx.bag_relu_gate, batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)),
             "mpo_coattn_mcat_backward")
         if colsum is not None:
@@ -383,7 +383,8 @@ class PatchCoAttnMCATFn(torch.autograd.Function):
     column sums = the patch layer's bias gradient) followed by the patch layer's weight gradient g^T X."""
 
     @staticmethod
-    def forward(ctx, x, patch_w, patch_b, query, in_w, in_b, out_w, out_b, batch: BagBatch, need_weights: bool, drop_p: float):
+    def forward(ctx, x, patch_w, patch_b, query, in_w, in_b, out_w, out_b, batch: BagBatch, need_weights: bool, drop_p: float,
+                tokens: "TokenPair | None" = None):
         lib = L.lib()
         ctx.set_materialize_grads(False)
         n_slides = batch.n_slides
@@ -392,7 +393,7 @@ class PatchCoAttnMCATFn(torch.autograd.Function):
         dev, T = query.device, batch.total_rows
         query = query.contiguous()
         h_bag = torch.empty(T, E, device=dev, dtype=torch.bfloat16)
-        out = torch.empty(R, E, device=dev, dtype=torch.float32)
+        out = tokens.slot(0, (R, E)) if tokens is not None else torch.empty(R, E, device=dev, dtype=torch.float32)
         amap = torch.empty(n_q * T, device=dev, dtype=torch.float32) if need_weights else None
         saved = torch.empty(lib.mpo_coattn_saved_floats(n_slides, n_q, E), device=dev, dtype=torch.float32)
         ws = _workspace(lib.mpo_patch_coattn_workspace_bytes(n_slides, n_q, E, x.shape[1]), dev)
@@ -407,10 +408,12 @@ class PatchCoAttnMCATFn(torch.autograd.Function):
         ctx.batch, ctx.n_q = batch, n_q
         ctx.gate = 1.0 / (1.0 - _realised_drop(drop_p)) if drop_p > 0 else 1.0
         ctx.mark_non_differentiable(h_bag)
-        return out, amap, h_bag
+        # the query handed on to its second consumer (the omic branch's tokens): its gradient then arrives HERE and is
+        # folded into the last GEMM of the backward (d_query += ...) instead of costing autograd an add launch
+        return out, amap, h_bag, query.view_as(query)
 
     @staticmethod
-    def backward(ctx, d_out, d_map, _d_h):
+    def backward(ctx, d_out, d_map, _d_h, d_qpass):
         lib = L.lib()
         x, h_bag, query, in_w, out_w, saved, amap = ctx.saved_tensors
         batch, n_q = ctx.batch, ctx.n_q
@@ -418,7 +421,8 @@ class PatchCoAttnMCATFn(torch.autograd.Function):
         dev = query.device
         d_out = d_out.contiguous() if d_out is not None else torch.zeros(R, E, device=dev)
         d_map = d_map.contiguous() if d_map is not None else None
-        d_query = torch.empty_like(query)
+        accumulate = d_qpass is not None
+        d_query = d_qpass.contiguous() if accumulate else torch.empty_like(query)    # (in place on the incoming gradient)
         g = torch.empty_like(h_bag)               # d(pre-activation of the patch layer): ReLU/dropout derivative applied in-kernel
         patch_w, patch_b, p_in_w, p_in_b, p_out_w, p_out_b = ctx.param_refs
         d_pw, d_pb = grad_out(patch_w), grad_out(patch_b)
@@ -426,16 +430,44 @@ class PatchCoAttnMCATFn(torch.autograd.Function):
         ws = _workspace(lib.mpo_coattn_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows), dev)
         L.check(lib.mpo_coattn_mcat_backward(
             L.ptr(h_bag), L.MPO_BF16, L.ptr(batch.cu), batch.n_slides, batch.total_rows, batch.max_rows, L.ptr(query), n_q, E,
-            L.ptr(in_w), L.ptr(out_w), L.ptr(saved), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), L.ptr(g),
-            L.ptr(d_pb), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w), L.ptr(d_out_b), ctx.gate, batch.plan(), L.ptr(ws),
-            ws.numel(), L.stream_of(query)), "mpo_coattn_mcat_backward")
+            L.ptr(in_w), L.ptr(out_w), L.ptr(saved), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_query), int(accumulate),
+            L.ptr(g), L.ptr(d_pb), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w), L.ptr(d_out_b), ctx.gate, batch.plan(),
+            L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_mcat_backward")
         stats["colsum_handoffs"] += 1
         if defer_patch_weight_grad and getattr(patch_w, "_mpo_grad_view", None) is not None \
                 and d_pw.data_ptr() == patch_w._mpo_grad_view.data_ptr():
             _deferred_patch.append((g, x, d_pw))   # filled by flush_patch_weight_grads() (data-parallel split exchange)
         else:
             _splitk_tn(g, x, d_pw)
-        return None, d_pw, d_pb, d_query, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None
+        return None, d_pw, d_pb, d_query, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None
+
+
+class TokenPair:
+    """(2, rows, d) fp32 buffer for the two token sets the branch-batched tail consumes (co-attention output | omic
+    tokens).  Producers write their half in place (`slot`), `stack` hands the whole buffer to the encoder: the
+    torch.stack copy and its backward disappear from the step."""
+
+    def __init__(self, rows: int, d: int, device):
+        self.buf = torch.empty(2, rows, d, device=device, dtype=torch.float32)
+
+    def slot(self, i: int, shape):
+        return self.buf[i].view(*shape)
+
+    def stack(self, first, second):
+        for i, t in enumerate((first, second)):
+            if t.data_ptr() != self.buf[i].data_ptr() or t.numel() != self.buf[i].numel() or not t.is_contiguous():
+                raise ValueError("TokenPair.stack: the halves must be the tensors produced into slot(0) and slot(1)")
+        return _TokenPairFn.apply(first, second, self)
+
+
+class _TokenPairFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, first, second, pair):
+        return pair.buf.view_as(pair.buf)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[0], d[1], None
 
 
 def _realised_drop(p: float) -> float:
@@ -444,9 +476,12 @@ def _realised_drop(p: float) -> float:
 
 
 def patch_coattn_mcat(x_bf16, batch: BagBatch, patch_w, patch_b, drop_p: float, query, in_w, in_b, out_w, out_b,
-                      need_weights: bool):
-    """-> (out (n_slides*n_q, E), ragged map | None, H_bag (rows, E) bf16, not differentiable)."""
-    return PatchCoAttnMCATFn.apply(x_bf16, patch_w, patch_b, query, in_w, in_b, out_w, out_b, batch, need_weights, float(drop_p))
+                      need_weights: bool, tokens: "TokenPair | None" = None):
+    """-> (out (n_slides*n_q, E), ragged map | None, H_bag (rows, E) bf16, not differentiable, query handed on).
+    tokens: `out` is produced into tokens.slot(0).  Use the returned query (not the argument) for the query's other
+    consumer: its gradient is then folded into this op's backward."""
+    return PatchCoAttnMCATFn.apply(x_bf16, patch_w, patch_b, query, in_w, in_b, out_w, out_b, batch, need_weights,
+                                   float(drop_p), tokens)
 
 
 def fused_patch_coattn_supported(x, embed: int, n_q: int) -> bool:
@@ -685,13 +720,14 @@ class OmicSnnFn(torch.autograd.Function):
     """self.G: all omic SNNs of a window in grouped launches (models/mcat/mcat.py:32-45,90-92)."""
 
     @staticmethod
-    def forward(ctx, drop_p, n_groups, *args):
+    def forward(ctx, drop_p, n_groups, tokens, *args):
         lib = L.lib()
         xs, params = [a.contiguous() for a in args[:n_groups]], args[n_groups:]
         n_slides, d = xs[0].shape[0], params[0].shape[0]
         dev = xs[0].device
         widths = (ctypes.c_int * n_groups)(*[int(x.shape[1]) for x in xs])
-        g_bag = torch.empty(n_slides, n_groups, d, device=dev, dtype=torch.float32)
+        g_bag = tokens.slot(1, (n_slides, n_groups, d)) if tokens is not None else \
+            torch.empty(n_slides, n_groups, d, device=dev, dtype=torch.float32)
         saved = torch.empty(lib.mpo_omic_snn_saved_floats(n_slides, n_groups, d), device=dev, dtype=torch.float32)
         seed, off = _reserve(lib.mpo_omic_snn_rng_span(n_slides, n_groups, d)) if drop_p > 0 else (0, 0)
         xa, pa = L.ptr_array(xs), L.ptr_array(params)
@@ -716,16 +752,17 @@ class OmicSnnFn(torch.autograd.Function):
         L.check(lib.mpo_omic_snn_backward(xa, widths, n, n_slides, d, pa, drop_p, seed, off, _epoch(), L.ptr(g_bag),
                                           L.ptr(saved), L.ptr(d_g.contiguous()), ga, L.ptr(ws), ws.numel(),
                                           L.stream_of(g_bag)), "mpo_omic_snn_backward")
-        return (None, None, *([None] * n), *grads)
+        return (None, None, None, *([None] * n), *grads)
 
 
-def omic_snn(omics, g_modules, training: bool):
-    """omics: per group (B, d_i) -> G_bag (B, N, d).  g_modules: the nn.ModuleList self.G (parameter holders)."""
+def omic_snn(omics, g_modules, training: bool, tokens: "TokenPair | None" = None):
+    """omics: per group (B, d_i) -> G_bag (B, N, d).  g_modules: the nn.ModuleList self.G (parameter holders).
+    tokens: G_bag is produced into tokens.slot(1)."""
     params = []
     for g in g_modules:
         params += [g[0][0].weight, g[0][0].bias, g[1][0].weight, g[1][0].bias]
     p = g_modules[0][0][2].p if training else 0.0
-    return OmicSnnFn.apply(p, len(omics), *[o.float() for o in omics], *params)
+    return OmicSnnFn.apply(p, len(omics), tokens, *[o.float() for o in omics], *params)
 
 
 class MapBlockNormFn(torch.autograd.Function):
@@ -881,6 +918,71 @@ def fusion_head_cat(hcat, fusion_layer, classifier):
     seq = fusion_layer.fusion_layer
     return FusionHeadFn.apply(hcat, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, classifier.weight,
                               classifier.bias)
+
+
+class FusionHeadLossFn(torch.autograd.Function):
+    """K6 + `ces` loss for a training step: ConcatFusion MLP + classifier GEMMs, then head, loss and the backward of both
+    in ONE launch.  The gradient the caller sends into the per-slide loss must be known up front: `slide_weight`
+    (B device floats; 1 / grad_acc_step in the reference's loop, models/mcat/main.py:69-70) -- backward() refuses any other
+    gradient tensor.  Returns (loss (B,), risk (B,), hazards, survs, Y); only `loss` carries gradient."""
+
+    @staticmethod
+    def forward(ctx, hcat, label, censorship, slide_weight, alpha, eps, *params):
+        lib = L.lib()
+        ctx.set_materialize_grads(False)
+        hcat = hcat.contiguous()
+        b, din = hcat.shape
+        hidden, dout, c = params[0].shape[0], params[2].shape[0], params[4].shape[0]
+        label = label.view(-1).to(torch.int64).contiguous()
+        censorship = censorship.view(-1).to(torch.float32).contiguous()
+        if slide_weight.shape != (b,) or slide_weight.dtype != torch.float32 or not slide_weight.is_contiguous():
+            raise ValueError("fusion_head_loss: slide_weight must be a contiguous fp32 tensor of one value per slide")
+        dev = hcat.device
+        hz = torch.empty(b, c, device=dev, dtype=torch.float32)
+        sv, y = torch.empty_like(hz), torch.empty_like(hz)
+        loss = torch.empty(b, device=dev, dtype=torch.float32)
+        risk = torch.empty(b, device=dev, dtype=torch.float32)
+        saved = torch.empty(lib.mpo_fusion_head_loss_saved_floats(b, hidden, dout, c), device=dev, dtype=torch.float32)
+        L.check(lib.mpo_fusion_head_loss_forward(
+            L.ptr(hcat), b, din, hidden, dout, c, L.ptr_array(params), L.ptr(label), L.ptr(censorship), L.ptr(slide_weight),
+            float(alpha), float(eps), L.ptr(hz), L.ptr(sv), L.ptr(y), L.ptr(loss), L.ptr(risk), L.ptr(saved),
+            L.stream_of(hcat)), "mpo_fusion_head_loss_forward")
+        ctx.save_for_backward(hcat, saved, slide_weight, *params)
+        ctx.param_refs = params
+        ctx.mark_non_differentiable(risk, hz, sv, y)
+        return loss, risk, hz, sv, y
+
+    @staticmethod
+    def backward(ctx, d_loss, *_unused):
+        lib = L.lib()
+        hcat, saved, slide_weight, *params = ctx.saved_tensors
+        if d_loss is None:
+            return (None,) * (6 + len(params))
+        if d_loss.data_ptr() != slide_weight.data_ptr() or d_loss.shape != slide_weight.shape:
+            raise RuntimeError("fusion_head_loss: backward() must be driven with the slide_weight tensor given to forward "
+                               "(the loss gradient is folded into the forward launch)")
+        b, din = hcat.shape
+        hidden, dout, c = params[0].shape[0], params[2].shape[0], params[4].shape[0]
+        d_hcat = torch.empty_like(hcat)
+        grads = [grad_out(p) for p in ctx.param_refs]
+        ws = _workspace(lib.mpo_fusion_head_workspace_bytes(b, hidden, dout, c), hcat.device)
+        L.check(lib.mpo_fusion_head_loss_backward(
+            L.ptr(hcat), b, din, hidden, dout, c, L.ptr_array(params), L.ptr(saved), L.ptr(d_hcat), L.ptr_array(grads),
+            L.ptr(ws), ws.numel(), L.stream_of(hcat)), "mpo_fusion_head_loss_backward")
+        return (d_hcat, None, None, None, None, None, *grads)
+
+
+def fusion_head_loss_cat(hcat, fusion_layer, classifier, label, censorship, slide_weight, alpha: float = 0.75, eps: float = 1e-7):
+    """Training-step K6: -> (per-slide `ces` loss, risk, hazards, survs, Y); drive backward with `slide_weight` itself."""
+    seq = fusion_layer.fusion_layer
+    return FusionHeadLossFn.apply(hcat, label, censorship, slide_weight, alpha, eps, seq[0].weight, seq[0].bias,
+                                  seq[2].weight, seq[2].bias, classifier.weight, classifier.bias)
+
+
+def bump_step_counters(rng_epoch=None, adam_step=None):
+    """rng_epoch (int64[1]) += 1 and adam_step (int32[1]) += 1 in one launch (either may be None)."""
+    t = rng_epoch if rng_epoch is not None else adam_step
+    L.check(L.lib().mpo_step_counters_bump(L.ptr(rng_epoch), L.ptr(adam_step), L.stream_of(t)), "mpo_step_counters_bump")
 
 
 # ------------------------------------------------------------------------------------ K2

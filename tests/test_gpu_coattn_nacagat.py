@@ -71,9 +71,11 @@ def test_nacagat_forward_backward(dev, golden, case, dtype):
     peaky = "peaky" in case
     assert relerr(out, out_o) < (1e-3 if peaky else 2e-4), relerr(out, out_o)
     rel_a = ((a.detach().cpu() - a_o.detach()).abs() / a_o.detach().clamp_min(1e-30)).max().item()
-    # fp32 bag: operands are bf16 hi+lo pairs (~2^-16 relative residual) and the gate multiplies that
-    # residual, dS = (g+1) da: the deliberately peaky fixture sits at ~1.3e-3, the others far below 1e-3
-    assert rel_a < (2e-3 if peaky else 1e-3), rel_a
+    # fp32 bag: both score products run on the fp32-input MFMA (bag_rowdot_gated_exact), so the map holds
+    # the north-star 1e-3 on the deliberately peaky fixture too; a bf16 bag reaches K through the bf16
+    # key projection, whose rounding the gate multiplies (dS = (g+1) da) on that fixture
+    print(f"[K2 map] {case} {dtype}: rel_a {rel_a:.3e}")
+    assert rel_a < (2e-3 if (peaky and not f32) else 1e-3), rel_a
     torch.testing.assert_close(a.sum(1).cpu(), torch.ones(C.N_OMIC), rtol=1e-4, atol=1e-4)
     params = dict(mod.named_parameters())
     tensors = [qd, bd] + [params[k[len("co_attention."):]] for k in p]
@@ -91,7 +93,7 @@ def test_nacagat_forward_backward(dev, golden, case, dtype):
         g = golden("coattn_nacagat")
         assert relerr(out, g[f"{case}/out"]) < 1e-3
         ga = g[f"{case}/A_sub"]
-        assert ((sub(a).cpu() - ga).abs() / ga.clamp_min(1e-30)).max().item() < 2e-3
+        assert ((sub(a).cpu() - ga).abs() / ga.clamp_min(1e-30)).max().item() < 1e-3
         for n, gr in zip(names, gs):
             ref = g[f"{case}/grad1/{n}"]
             assert relerr(sub(gr), ref) < (6e-3 if peaky else 3e-3), (n, relerr(sub(gr), ref))

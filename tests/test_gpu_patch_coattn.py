@@ -39,9 +39,9 @@ def _fused(p, bags, query, dev, need_weights=True, drop_p=0.0, n_q=N_Q):
     batch = BagBatch.from_list([b.to(dev).to(torch.bfloat16) for b in bags])
     d = {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
     q = query.to(dev).requires_grad_(True)
-    out, amap, h = ops.patch_coattn_mcat(batch.data, batch, d["H.0.weight"], d["H.0.bias"], drop_p, q,
-                                         d["co_attention.in_proj_weight"], d["co_attention.in_proj_bias"],
-                                         d["co_attention.out_proj.weight"], d["co_attention.out_proj.bias"], need_weights)
+    out, amap, h, _ = ops.patch_coattn_mcat(batch.data, batch, d["H.0.weight"], d["H.0.bias"], drop_p, q,
+                                            d["co_attention.in_proj_weight"], d["co_attention.in_proj_bias"],
+                                            d["co_attention.out_proj.weight"], d["co_attention.out_proj.bias"], need_weights)
     return out, amap, h, d, q, batch
 
 
@@ -210,3 +210,47 @@ def test_fused_dropout_masks(dev):
     torch.cat(outs).sum().backward()
     assert relmax(d1["H.0.weight"].grad.cpu(), pr["H.0.weight"].grad) < 2e-2
     assert relmax(d1["H.0.bias"].grad.cpu(), pr["H.0.bias"].grad) < 2e-2
+
+
+class _ProduceInto(torch.autograd.Function):
+    """Test stand-in for the omic SNN: a producer that writes its output into the pair's second half."""
+
+    @staticmethod
+    def forward(ctx, q, pair):
+        dst = pair.slot(1, q.shape)
+        dst.copy_(q)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def test_token_pair_hands_both_token_sets_over_without_copies(dev):
+    """ops.TokenPair: the co-attention output and the (doubly used) query land in one (2, R, E) buffer and the query's
+    second gradient is folded into the op's own backward (d_query accumulate): values and gradients must equal the
+    torch.stack formulation."""
+    lengths = [700, 333]
+    p = _params(31)
+    bags, query = _inputs(lengths, 77)
+    probe = syn.normal(syn.rng(5), (2, len(lengths) * N_Q, E)).to(dev)
+
+    def run(use_pair):
+        batch = BagBatch.from_list([b.to(dev).to(torch.bfloat16) for b in bags])
+        d = {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
+        q = query.to(dev).requires_grad_(True)
+        pair = ops.TokenPair(q.shape[0], E, dev) if use_pair else None
+        q_in = _ProduceInto.apply(q, pair) if use_pair else q * 1.0
+        out, _, _, q_tok = ops.patch_coattn_mcat(batch.data, batch, d["H.0.weight"], d["H.0.bias"], 0.0, q_in,
+                                                 d["co_attention.in_proj_weight"], d["co_attention.in_proj_bias"],
+                                                 d["co_attention.out_proj.weight"], d["co_attention.out_proj.bias"], False, pair)
+        stacked = pair.stack(out, q_tok) if use_pair else torch.stack([out, q_tok])
+        (stacked * probe).sum().backward()
+        return stacked.detach().clone(), q.grad.clone(), {k: v.grad.clone() for k, v in d.items()}
+
+    s0, gq0, g0 = run(False)
+    s1, gq1, g1 = run(True)
+    assert torch.equal(s0, s1)
+    torch.testing.assert_close(gq1, gq0, rtol=1e-5, atol=1e-6)
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=1e-5, atol=1e-6)
