@@ -404,16 +404,18 @@ __device__ __forceinline__ void tanh_frag(bf16x8 xh, bf16x8 xl, bf16x8& th, bf16
 // per-slide LDS tables [k/4][column 0..7][4] (16-byte entries, broadcast reads): qs and -2*tq, with
 // tanh(x) = 1 - 2r, r = 1/(2^(2x log2 e) + 1) folded as g = sum(tq) - 2 sum(r tq).  Eight waves per CU, tiles staged
 // through registers (NOTES.md r02-K2: the direct-to-LDS form with 8-row tiles has half the bytes in flight and is slower).
-template <int E_>
+template <int E_, int NG>                                    // NG column groups of four queries: 2 (N <= 8) or 4 (N <= 16)
 struct GateCfg {
-    static constexpr int WAVES = 8;
+    static constexpr int WAVES = NG <= 2 ? 8 : 4;            // the wider operand tables leave room for four tiles
+    static constexpr int PAIRS = WAVES / 2;                  // a wave pair shares one of the plan's 32-row tiles
     static constexpr int ROWS = 16;
     static constexpr int ROWB = E_ * 4 + 16;
     static constexpr int TILEB = ROWS * ROWB;
-    static constexpr int TAB = (E_ / 4) * 8 * 16;
+    static constexpr int NCOL = 4 * NG;
+    static constexpr int TAB = (E_ / 4) * NCOL * 16;
     static constexpr int OFF_TAB = WAVES * TILEB;
     static constexpr int OFF_SUM = OFF_TAB + 2 * TAB;
-    static constexpr int LDS_BYTES = OFF_SUM + 64;           // E = 256: 149 568 bytes
+    static constexpr int LDS_BYTES = OFF_SUM + 64;           // E = 256: 149 568 (NG = 2) / 132 160 (NG = 4) bytes
     static constexpr int CH = E_ / 4;                        // 16-byte chunks per row
     static constexpr int NLD = ROWS * CH / 64;               // global loads per lane per tile
     static constexpr int KU = E_ / 16;
@@ -421,22 +423,22 @@ struct GateCfg {
 
 template <int E_>
 struct GateStage {
-    using C = GateCfg<E_>;
-    f32x4 v[C::NLD];
+    static constexpr int ROWS = 16, ROWB = E_ * 4 + 16, CH = E_ / 4, NLD = ROWS * CH / 64;
+    f32x4 v[NLD];
     __device__ __forceinline__ void load(const char* slide, int row0, int m_rows, int lane) {
 #pragma unroll
-        for (int i = 0; i < C::NLD; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const int ci = i * 64 + lane;
-            int grow = row0 + ci / C::CH;
+            int grow = row0 + ci / CH;
             grow = grow < m_rows ? grow : m_rows - 1;
-            v[i] = *reinterpret_cast<const f32x4*>(slide + ((size_t)grow * C::CH + ci % C::CH) * 16);
+            v[i] = *reinterpret_cast<const f32x4*>(slide + ((size_t)grow * CH + ci % CH) * 16);
         }
     }
     __device__ __forceinline__ void store(char* tile, int lane) const {
 #pragma unroll
-        for (int i = 0; i < C::NLD; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const int ci = i * 64 + lane;
-            *reinterpret_cast<f32x4*>(tile + (ci / C::CH) * C::ROWB + (ci % C::CH) * 16) = v[i];
+            *reinterpret_cast<f32x4*>(tile + (ci / CH) * ROWB + (ci % CH) * 16) = v[i];
         }
     }
 };
@@ -456,20 +458,20 @@ __device__ __forceinline__ float pick(f32x4 v, int p) {
     return p == 0 ? v[0] : p == 1 ? v[1] : p == 2 ? v[2] : v[3];
 }
 
-template <int E_>
-__global__ __launch_bounds__(GateCfg<E_>::WAVES * 64, 1)
+template <int E_, int NG>
+__global__ __launch_bounds__((GateCfg<E_, NG>::WAVES * 64), 1)
 void bag_rowdot_gated_exact_kernel(const float* __restrict__ bag, const int* __restrict__ cu,
                                    const float* __restrict__ r1, const float* __restrict__ r2,
                                    float* __restrict__ a_map, float* __restrict__ g_map, int n_q, BagPlan plan) {
-    using C = GateCfg<E_>;
+    using C = GateCfg<E_, NG>;
     __shared__ __attribute__((aligned(16))) char lds[C::LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const SplitGeom sg = split_geom<4>(cu, plan, wave >> 1);          // a wave pair shares the plan's 32-row tiles
+    const SplitGeom sg = split_geom<C::PAIRS>(cu, plan, wave >> 1);
     char* tile = lds + wave * C::TILEB;
     // operand tables of this slide: entry (k4, col) = r[col][4 k4 .. +3], zero for col >= n_q
-    for (int idx = threadIdx.x; idx < (E_ / 4) * 8; idx += C::WAVES * 64) {
-        const int k4 = idx >> 3, col = idx & 7;
+    for (int idx = threadIdx.x; idx < (E_ / 4) * C::NCOL; idx += C::WAVES * 64) {
+        const int k4 = idx / C::NCOL, col = idx % C::NCOL;
         f32x4 va = {0.f, 0.f, 0.f, 0.f}, vg = va;
         if (col < n_q) {
             va = *reinterpret_cast<const f32x4*>(r1 + ((size_t)sg.b * n_q + col) * E_ + 4 * k4);
@@ -478,8 +480,8 @@ void bag_rowdot_gated_exact_kernel(const float* __restrict__ bag, const int* __r
         *reinterpret_cast<f32x4*>(lds + C::OFF_TAB + idx * 16) = va;
         *reinterpret_cast<f32x4*>(lds + C::OFF_TAB + C::TAB + idx * 16) = vg;
     }
-    if (wave == 0) {                                                   // sum_e tq[col][e]: eight lanes per column
-        const int col = lane >> 3, part = lane & 7;
+    for (int col = wave * 8 + (lane >> 3); col < C::NCOL; col += C::WAVES * 8) {   // sum_e tq[col][e]: eight lanes per column
+        const int part = lane & 7;
         float acc = 0.f;
         if (col < n_q)
             for (int e = part; e < E_; e += 8) acc += r2[((size_t)sg.b * n_q + col) * E_ + e];
@@ -491,50 +493,54 @@ void bag_rowdot_gated_exact_kernel(const float* __restrict__ bag, const int* __r
     __syncthreads();
     const int row = lane & 15, ph = lane >> 4;
     const char* arow = tile + row * C::ROWB + 16 * ph;
-    const char* btab = lds + C::OFF_TAB + (ph * 8 + (lane & 3)) * 16;
+    const char* btab = lds + C::OFF_TAB + (ph * C::NCOL + (lane & 3)) * 16;
     const char* slide = reinterpret_cast<const char*>(bag) + (size_t)sg.row_begin * E_ * 4;
     const int half = C::ROWS * (wave & 1);
     const int orow = 4 * ((lane >> 2) & 3) + ph;                       // the output row this lane stores
-    const int c0 = lane & 3, c1 = 4 + (lane & 3);
-    const float st0 = reinterpret_cast<const float*>(lds + C::OFF_SUM)[c0];
-    const float st1 = reinterpret_cast<const float*>(lds + C::OFF_SUM)[c1];
+    float osum[NG];
+#pragma unroll
+    for (int c = 0; c < NG; ++c) osum[c] = reinterpret_cast<const float*>(lds + C::OFF_SUM)[4 * c + (lane & 3)];
     float* am = a_map + (size_t)n_q * sg.row_begin;
     float* gm = g_map + (size_t)n_q * sg.row_begin;
     GateStage<E_> st;
     if (sg.n_my > 0) st.load(slide, sg.r0 + kTileRows * (wave >> 1) + half, sg.m_rows, lane);
     for (int it = 0; it < sg.n_my; ++it) {
-        const int trow = sg.r0 + kTileRows * ((wave >> 1) + it * 4) + half;
+        const int trow = sg.r0 + kTileRows * ((wave >> 1) + it * C::PAIRS) + half;
         const int nvalid = min(C::ROWS, sg.r1 - trow);                 // may be <= 0 for the upper half of a last tile
         st.store(tile, lane);
-        if (it + 1 < sg.n_my) st.load(slide, trow + kTileRows * 4, sg.m_rows, lane);
+        if (it + 1 < sg.n_my) st.load(slide, trow + kTileRows * C::PAIRS, sg.m_rows, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, g0 = a0, g1 = a0;
+        f32x4 a[NG], g[NG];
+#pragma unroll
+        for (int c = 0; c < NG; ++c) a[c] = g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < C::KU; ++u) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(arow + 64 * u);
-            const f32x4 qa0 = *reinterpret_cast<const f32x4*>(btab + 512 * u);
-            const f32x4 qa1 = *reinterpret_cast<const f32x4*>(btab + 512 * u + 64);
-            const f32x4 qg0 = *reinterpret_cast<const f32x4*>(btab + C::TAB + 512 * u);
-            const f32x4 qg1 = *reinterpret_cast<const f32x4*>(btab + C::TAB + 512 * u + 64);
+            f32x4 qa[NG], qg[NG];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                qa[c] = *reinterpret_cast<const f32x4*>(btab + (4 * C::NCOL * 16) * u + 64 * c);
+                qg[c] = *reinterpret_cast<const f32x4*>(btab + C::TAB + (4 * C::NCOL * 16) * u + 64 * c);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[j] * (2.0f * kLog2e)) + 1.0f);
-                a0 = mfma_4x4(x[j], qa0[j], a0);
-                a1 = mfma_4x4(x[j], qa1[j], a1);
-                g0 = mfma_4x4(r, qg0[j], g0);
-                g1 = mfma_4x4(r, qg1[j], g1);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    a[c] = mfma_4x4(x[j], qa[c][j], a[c]);
+                    g[c] = mfma_4x4(r, qg[c][j], g[c]);
+                }
             }
         }
-        a0 = sum_phases(a0); a1 = sum_phases(a1); g0 = sum_phases(g0); g1 = sum_phases(g1);
-        if (orow < nvalid) {
-            if (c0 < n_q) {
-                am[(size_t)c0 * sg.m_rows + trow + orow] = pick(a0, ph);
-                gm[(size_t)c0 * sg.m_rows + trow + orow] = pick(g0, ph) + st0;
-            }
-            if (c1 < n_q) {
-                am[(size_t)c1 * sg.m_rows + trow + orow] = pick(a1, ph);
-                gm[(size_t)c1 * sg.m_rows + trow + orow] = pick(g1, ph) + st1;
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            a[c] = sum_phases(a[c]);
+            g[c] = sum_phases(g[c]);
+            const int col = 4 * c + (lane & 3);
+            if (orow < nvalid && col < n_q) {
+                am[(size_t)col * sg.m_rows + trow + orow] = pick(a[c], ph);
+                gm[(size_t)col * sg.m_rows + trow + orow] = pick(g[c], ph) + osum[c];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1260,7 +1266,12 @@ int mpo_launch_bag_rowdot_gated(const void* bag, int bag_f32, const int* cu, int
     (void)n_slides;
     dim3 grid = plan_grid(plan);
     MPO_CHECK(bag_f32, "bag_rowdot_gated: the key bag is fp32 (K2 projects bf16 bags into fp32 keys first)");
-    MPO_E_SWITCH(embed, (bag_rowdot_gated_exact_kernel<EV><<<grid, GateCfg<EV>::WAVES * 64, 0, stream>>>(static_cast<const float*>(bag), cu, r1, r2, a_map, g_map, n_q, plan)))
+    MPO_CHECK(n_q >= 1 && n_q <= 16, "bag_rowdot_gated: 1..16 queries (got %d)", n_q);
+    if (n_q <= 8) {
+        MPO_E_SWITCH(embed, (bag_rowdot_gated_exact_kernel<EV, 2><<<grid, GateCfg<EV, 2>::WAVES * 64, 0, stream>>>(static_cast<const float*>(bag), cu, r1, r2, a_map, g_map, n_q, plan)))
+    } else {
+        MPO_E_SWITCH(embed, (bag_rowdot_gated_exact_kernel<EV, 4><<<grid, GateCfg<EV, 4>::WAVES * 64, 0, stream>>>(static_cast<const float*>(bag), cu, r1, r2, a_map, g_map, n_q, plan)))
+    }
     MPO_LAUNCH_CHECK();
     return 0;
 }

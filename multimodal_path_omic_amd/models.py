@@ -102,7 +102,7 @@ class _FusionModelBase(nn.Module):
         pair = self._token_pair(bags, omics)
         g_bag = self._omic_fc(omics, pair)
         h_coattn, a_coattn, g_tok = self._patch_and_co_attend(g_bag, bags, inference, pair)
-        stacked = pair.stack(h_coattn, g_tok) if pair is not None else torch.stack([h_coattn, g_tok])
+        stacked = pair.stack(h_coattn, g_tok).view(2, *h_coattn.shape) if pair is not None else torch.stack([h_coattn, g_tok])
         tokens = ops.encoder_stacked(stacked, [list(self.path_transformer.layers), list(self.omic_transformer.layers)],
                                      self.training)
         a, h = ops.gated_pool_stacked(tokens, [self.path_attention_head, self.omic_attention_head],

@@ -463,11 +463,12 @@ class TokenPair:
 class _TokenPairFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, first, second, pair):
+        ctx.shapes = (first.shape, second.shape)
         return pair.buf.view_as(pair.buf)
 
     @staticmethod
     def backward(ctx, d):
-        return d[0], d[1], None
+        return d[0].view(ctx.shapes[0]), d[1].view(ctx.shapes[1]), None
 
 
 def _realised_drop(p: float) -> float:
