@@ -388,12 +388,14 @@ def main():
     torch.cuda.set_device(dev)
 
     out = run_config(a, dev, rank, world, a.steps, a.warmup)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_leg(a.model, a.patches)
     if not a.no_extras and not a.ragged and a.model == "mcat" and a.patches == 15000 and a.dtype == "bf16":
         ex = extras(a, dev, rank, world)
         if rank == 0:
             out["extra"] = ex
+    # the CPU leg comes LAST: ~20 s of 64 busy host threads right before a GPU leg left that leg's first seconds slow
+    # (measured: the ragged extra at 1.92 ms per step after it, 1.47 ms before it)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_leg(a.model, a.patches)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -436,15 +436,40 @@ void bag_finish_kernel(BagFinish f, int n_slides, int per_slide, BagPlan plan) {
         for (int k = 0; k < 2; ++k)
             if (f.zero[k])
                 for (int i = tid; i < f.n_zero[k]; i += nthr) f.zero[k][i] = 0.f;
-        if (f.part_cs == nullptr || 4 * (int)blockIdx.x * 64 >= f.cs_cols) return;
+        // column sums over ALL partials: a workgroup takes 8 float4 columns, its 32 thread groups stride the partials
+        // (8 independent loads per thread at 256 partials), one exchange through LDS
+        const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+        const int col4 = blockIdx.x * 8 + c8;
+        if (f.part_cs == nullptr || 4 * (int)blockIdx.x * 8 >= f.cs_cols) return;
+        const int parts = (int)plan_parts_dev(plan);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (4 * col4 < f.cs_cols) {
+#pragma unroll 8
+            for (int s = pl; s < parts; s += 32) a += *reinterpret_cast<const f32x4*>(f.part_cs + (size_t)s * f.cs_cols + 4 * col4);
+        }
+        f32x4* red4 = reinterpret_cast<f32x4*>(&red[0][0]);
+        red4[threadIdx.x] = a;
+        __syncthreads();
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};                            // 4 x 8 partial sums per column, then one thread adds the four
+        if (pl < 4) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red4[(pl * 8 + k) * 8 + c8];
+        }
+        __syncthreads();                                           // every read of the first round is done before slots are reused
+        if (pl < 4) red4[threadIdx.x] = t;
+        __syncthreads();
+        if (pl == 0 && 4 * col4 < f.cs_cols) {
+            const f32x4 tot = (red4[c8] + red4[8 + c8]) + (red4[16 + c8] + red4[24 + c8]);
+            *reinterpret_cast<f32x4*>(f.colsum + 4 * col4) = tot;
+        }
+        return;
     }
-    const int which = extra ? 0 : (int)blockIdx.y / n_slides, b = extra ? 0 : (int)blockIdx.y % n_slides;
-    const float* part = extra ? f.part_cs : f.part[which];
-    float* out = extra ? f.colsum : f.out[which] + (size_t)b * per_slide;
-    const int width = extra ? f.cs_cols : per_slide;
+    const int which = (int)blockIdx.y / n_slides, b = (int)blockIdx.y % n_slides;
+    const float* part = f.part[which];
+    float* out = f.out[which] + (size_t)b * per_slide;
+    const int width = per_slide;
     int s0, s1;
-    if (extra) { s0 = 0; s1 = (int)plan_parts_dev(plan); }
-    else slide_parts(plan, b, s0, s1);
+    slide_parts(plan, b, s0, s1);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (4 * i4 < width)
         for (int s = s0 + w; s < s1; s += 4)
@@ -546,7 +571,7 @@ int mpo_launch_bag_finish(const BagFinish& f, int n_slides, int n_q, int embed, 
     MPO_CHECK((embed & 3) == 0 && (f.cs_cols & 3) == 0, "bag finish: widths must be multiples of 4");
     const int per = n_q * embed;
     int bx = f.n_red ? (per / 4 + 63) / 64 : 1;
-    if (f.part_cs) bx = max(bx, (f.cs_cols / 4 + 63) / 64);
+    if (f.part_cs) bx = max(bx, (f.cs_cols / 4 + 7) / 8);
     if (f.zero[0] || f.zero[1]) bx = max(bx, 8);
     dim3 grid(bx, n_slides * f.n_red + 1);
     bag_finish_kernel<<<grid, 256, 0, stream>>>(f, n_slides, per, plan);
