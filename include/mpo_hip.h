@@ -140,6 +140,15 @@ int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g
 /* out[c] = sum_r x[r][c] for a bf16 [rows, cols] tensor: the bias gradient of self.H (torch's reduce: 142 us) */
 int mpo_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, mpo_stream_t stream);
 
+/* ---- weight gradient of self.H (models/mcat/mcat.py:24-29: Linear(1024, 256)): d_weight [embed, patch_dim] fp32 =
+ * g^T X over the whole window, g [rows, embed] bf16 = gradient w.r.t. the layer's pre-activation (what
+ * mpo_coattn_mcat_backward with bag_relu_gate / mpo_nacagat_patch_grad / mpo_patch_epilogue_backward emit), X the raw bf16
+ * patch matrix.  Hand-written split-row kernel (one workgroup per CU, fp32 partials in the workspace + a reduction
+ * launch).  Built for embed 256 and patch_dim a multiple of 256 (256 ... 2048). */
+size_t mpo_patch_weight_grad_workspace_bytes(int embed, int patch_dim);
+int mpo_patch_weight_grad(const void* g_bf16, const void* patches_bf16, int64_t total_rows, int embed, int patch_dim,
+                          float* d_weight, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
 /* ---- optimiser step of the reference's default `adam` (models/mcat/main.py:284-300: torch.optim.Adam(lr, weight_decay))
  * over ONE flat parameter / gradient / moment buffer: g' = g + wd p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
  * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */

@@ -529,6 +529,21 @@ int mpo_patch_epilogue_backward(const void* h_bf16, const void* dy_bf16, void* g
     return mpo_launch_colsum(part, d_bias, mpo_relu_dropout_bwd_blocks((size_t)n, 1), cols, cols, 0, stream);
 }
 
+// dW_H = g^T X (models/mcat/mcat.py:24-29 backward): g = d(pre-activation) [rows, embed] bf16, X [rows, patch_dim] bf16
+size_t mpo_patch_weight_grad_workspace_bytes(int embed, int patch_dim) {
+    return mpo_patch_wgrad_partial_floats(embed, patch_dim) * sizeof(float) + 256;
+}
+int mpo_patch_weight_grad(const void* g_bf16, const void* patches_bf16, int64_t total_rows, int embed, int patch_dim,
+                          float* d_weight, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    MPO_CHECK(g_bf16 && patches_bf16 && d_weight, "patch weight gradient: null argument");
+    MPO_CHECK(total_rows >= 1 && total_rows < (int64_t)1 << 31, "patch weight gradient: %lld rows", (long long)total_rows);
+    Arena ws(workspace, workspace_bytes);
+    float* part = ws.floats(mpo_patch_wgrad_partial_floats(embed, patch_dim));
+    MPO_CHECK(part, "patch weight gradient: workspace too small (%zu bytes)", workspace_bytes);
+    return mpo_launch_patch_wgrad(g_bf16, patches_bf16, (int)total_rows, embed, patch_dim, part, d_weight,
+                                  static_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------------------------------- optimiser
 int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int step, const int32_t* step_dev,

@@ -156,6 +156,10 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
                           const float* ctx, const float* a_map, const float* da_map,
                           void* dbag, float* part_dqk, float* part_colsum /* nullable [parts][E] */, int n_q, const BagPlan& plan,
                           float relu_gate, hipStream_t stream);
+// dW_H = g^T X of the patch layer, hand-written (patch_wgrad.hip): part = mpo_patch_wgrad_partial_floats() floats
+size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim);
+int mpo_launch_patch_wgrad(const void* g_bf16, const void* x_bf16, int total_rows, int embed, int patch_dim, float* part,
+                           float* d_weight, hipStream_t stream);
 // what follows a split-M bag pass, one launch: up to two per-slide reductions of [parts][n_q*E] partials, the column
 // sums over all partials of a [parts][cs_cols] array, zero-fills of up to two regions (coattn_bwd.hip: bag_finish_kernel)
 struct BagFinish {

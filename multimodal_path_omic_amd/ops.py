@@ -275,7 +275,7 @@ _deferred_patch = []
 def flush_patch_weight_grads():
     """Compute the patch-layer weight gradients PatchFcFn.backward queued (into the bucket slices it already returned)."""
     for g, x, dw in _deferred_patch:
-        _splitk_tn(g, x, dw)
+        patch_weight_grad(g, x, dw)
     _deferred_patch.clear()
 
 
@@ -329,7 +329,7 @@ class PatchFcFn(torch.autograd.Function):
                 and dw.data_ptr() == ctx.param_refs[0]._mpo_grad_view.data_ptr():
             _deferred_patch.append((g, x, dw))      # dw aliases the bucket slice: filled by flush_patch_weight_grads()
         else:
-            _splitk_tn(g, x, dw)
+            patch_weight_grad(g, x, dw)
         return None, dw, db, None, None
 
 
@@ -373,6 +373,20 @@ def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk
     if main < rows:
         out += torch.mm(g[main:].t(), x[main:], out_dtype=torch.float32)
     return out
+
+
+def patch_weight_grad(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """dW_H = g^T x into `out` (embed, patch_dim) fp32: the hand-written kernel (mpo_patch_weight_grad) for a bf16 window
+    at embed 256 / patch_dim a multiple of 256, the library split-K product otherwise."""
+    e, k = out.shape
+    if (g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and e == 256 and k % 256 == 0 and 256 <= k <= 2048
+            and g.is_contiguous() and x.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32):
+        lib = L.lib()
+        ws = _workspace(lib.mpo_patch_weight_grad_workspace_bytes(e, k), g.device)
+        L.check(lib.mpo_patch_weight_grad(L.ptr(g), L.ptr(x), g.shape[0], e, k, L.ptr(out), L.ptr(ws), ws.numel(),
+                                          L.stream_of(g)), "mpo_patch_weight_grad")
+        return out
+    return _splitk_tn(g, x, out)
 
 
 # ------------------------------------------------------------------------------------ row f1: patch layer + K1 in one pass
@@ -438,7 +452,7 @@ class PatchCoAttnMCATFn(torch.autograd.Function):
                 and d_pw.data_ptr() == patch_w._mpo_grad_view.data_ptr():
             _deferred_patch.append((g, x, d_pw))   # filled by flush_patch_weight_grads() (data-parallel split exchange)
         else:
-            _splitk_tn(g, x, d_pw)
+            patch_weight_grad(g, x, d_pw)
         return None, d_pw, d_pb, d_query, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None, None
 
 
