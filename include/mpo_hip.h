@@ -261,10 +261,13 @@ size_t mpo_gated_pool_workspace_bytes(int n_slides, int L, int d);
 uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d);
 int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                            float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
-                           float* scores, float* h, float* saved, mpo_stream_t stream);
+                           float* scores, float* h, int h_interleaved, float* saved, mpo_stream_t stream);
+/* h_interleaved != 0: h (and dh in the backward) are [n_slides][n_branches][d] -- with the path and the omic branch batched
+ * that IS the concatenated [h_path | h_omic] row ConcatFusion reads (models/fusion.py:17-19), no transposing copy. */
 int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                             float head_drop_p, float rho_drop_p, const float* saved, const float* h,
-                            const float* dh, const float* d_scores_ext /* nullable */, float* dx, float* const* grads,
+                            const float* dh, int h_interleaved, const float* d_scores_ext /* nullable */, float* dx,
+                            float* const* grads,
                             void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ---- K6: ConcatFusion (models/fusion.py:7-19) + classifier + survival head (models/mcat/mcat.py:119-138).

@@ -79,8 +79,8 @@ _SIGNATURES = {
     "mpo_gated_pool_saved_floats": (c_size_t, [c_int] * 3),
     "mpo_gated_pool_workspace_bytes": (c_size_t, [c_int] * 3),
     "mpo_gated_pool_rng_span": (c_uint64, [c_int] * 3),
-    "mpo_gated_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_float, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P]),
-    "mpo_gated_pool_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_gated_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_float, c_float, c_uint64, c_uint64, _P, _P, _P, c_int, _P, _P]),
+    "mpo_gated_pool_backward": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_fusion_head_saved_floats": (c_size_t, [c_int] * 4),
     "mpo_fusion_head_workspace_bytes": (c_size_t, [c_int] * 4),
     "mpo_fusion_head_forward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P, _P, _P]),

@@ -275,8 +275,9 @@ uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d) { return 3 * ((uint
 // scores = W_c[drop(tanh(W_a x)) * drop(sigmoid(W_b x))] + b_c; h = drop(relu(W_rho (softmax_L(scores) x) + b_rho))
 int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                            float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
-                           float* scores, float* h, float* saved, mpo_stream_t stream) {
+                           float* scores, float* h, int h_interleaved, float* saved, mpo_stream_t stream) {
     MPO_CHECK(n_branches >= 1 && n_branches <= kMaxBranches, "gated pool: 1..%d branches (got %d)", kMaxBranches, n_branches);
+    MPO_CHECK(!h_interleaved || (d & 3) == 0, "gated pool: interleaved h needs d %% 4 == 0 (got %d)", d);
     const int NB = n_branches, R = n_slides * L, RT = NB * R, BT = NB * n_slides;
     const uint64_t stride = (uint64_t)RT * d / 4 + 2 + kMaxBranches;
     const size_t Rd = (size_t)R * d, Bd = (size_t)n_slides * d;
@@ -291,8 +292,19 @@ int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, 
         RC(gab.add(mpo_args_fwd(x + br * Rd, P(br, 0), P(br, 1), a + br * Rd, R, d, d, 1.0f, MPO_ACT_TANH, nullptr, drop_br(s0, br, Rd))));
         RC(gab.add(mpo_args_fwd(x + br * Rd, P(br, 2), P(br, 3), b + br * Rd, R, d, d, 1.0f, MPO_ACT_SIGMOID, nullptr, drop_br(s1, br, Rd))));
         RC(gsc.add(mpo_args_fwd(ab + br * Rd, P(br, 4), P(br, 5), scores + (size_t)br * R, R, d, 1, 1.0f, MPO_ACT_NONE)));
-        RC(grho.add(mpo_args_fwd(hpool + br * Bd, P(br, 6), P(br, 7), h + br * Bd, n_slides, d, d, 1.0f, MPO_ACT_RELU, nullptr,
-                                 drop_br(s2, br, Bd))));
+        if (h_interleaved) {
+            // h [n_slides][branch][d] = the concatenated [h_path | h_omic] rows the fusion layer reads (no transposing copy);
+            // one dropout stream over the interleaved rows: branch br starts d / 4 counters in
+            DropSpec sd = s2;
+            sd.off += (uint64_t)br * (d / 4);
+            GemmArgs m = mpo_args_fwd(hpool + br * Bd, P(br, 6), P(br, 7), h + (size_t)br * d, n_slides, d, d, 1.0f, MPO_ACT_RELU,
+                                      nullptr, sd);
+            m.ldc = NB * d;
+            RC(grho.add(m));
+        } else {
+            RC(grho.add(mpo_args_fwd(hpool + br * Bd, P(br, 6), P(br, 7), h + br * Bd, n_slides, d, d, 1.0f, MPO_ACT_RELU, nullptr,
+                                     drop_br(s2, br, Bd))));
+        }
     }
     RC(gab.launch(stream));
     RC(mpo_launch_ew_mul(a, b, ab, RT * d, stream));
@@ -304,7 +316,7 @@ int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, 
 
 int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                             float head_drop_p, float rho_drop_p, const float* saved, const float* h,
-                            const float* dh, const float* d_scores_ext, float* dx, float* const* grads,
+                            const float* dh, int h_interleaved, const float* d_scores_ext, float* dx, float* const* grads,
                             void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     MPO_CHECK(n_branches >= 1 && n_branches <= 2, "gated pool backward: 1..2 branches (got %d)", n_branches);
     const int NB = n_branches, R = n_slides * L, RT = NB * R, BT = NB * n_slides;
@@ -330,9 +342,11 @@ int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L,
         RC(main_g.launch(stream));
         return 0;
     };
-    // h = drop(relu(hpool W_rho^T + b_rho))
-    RC(pairs([&](int br) { return mpo_args_bwd_input(dh + br * Bd, P(br, 6), dhpool + br * Bd, n_slides, d, d, 1.0f, 0, gate(h + br * Bd, MPO_GATE_RELU, rho_drop_p)); },
-             [&](int br) { return mpo_args_bwd_weight(dh + br * Bd, hpool + br * Bd, G(br, 6), G(br, 7), n_slides, d, d, 1.0f, gate(h + br * Bd, MPO_GATE_RELU, rho_drop_p)); }));
+    // h = drop(relu(hpool W_rho^T + b_rho));  h / dh either [branch][n_slides][d] or interleaved [n_slides][branch][d]
+    const size_t h_off = h_interleaved ? (size_t)d : Bd;
+    const int h_ld = h_interleaved ? NB * d : d;
+    RC(pairs([&](int br) { GemmArgs m = mpo_args_bwd_input(dh + br * h_off, P(br, 6), dhpool + br * Bd, n_slides, d, d, 1.0f, 0, gate(h + br * h_off, MPO_GATE_RELU, rho_drop_p)); m.lda = h_ld; return m; },
+             [&](int br) { GemmArgs m = mpo_args_bwd_weight(dh + br * h_off, hpool + br * Bd, G(br, 6), G(br, 7), n_slides, d, d, 1.0f, gate(h + br * h_off, MPO_GATE_RELU, rho_drop_p)); m.lda = h_ld; return m; }));
     RC(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, BT, L, d, stream));
     // scores = ab W_c^T + b_c
     RC(pairs([&](int br) { return mpo_args_bwd_input(dscores + (size_t)br * R, P(br, 4), dab + br * Rd, R, d, 1, 1.0f, 0); },

@@ -105,26 +105,26 @@ class _FusionModelBase(nn.Module):
         stacked = pair.stack(h_coattn, g_tok).view(2, *h_coattn.shape) if pair is not None else torch.stack([h_coattn, g_tok])
         tokens = ops.encoder_stacked(stacked, [list(self.path_transformer.layers), list(self.omic_transformer.layers)],
                                      self.training)
+        concat = self.fusion == "concat"
         a, h = ops.gated_pool_stacked(tokens, [self.path_attention_head, self.omic_attention_head],
-                                      [self.path_rho, self.omic_rho], self.training)
+                                      [self.path_rho, self.omic_rho], self.training, interleave=concat)
         att = {"coattn": a_coattn, "path": a[0], "omic": a[1]}
         if ces_targets is not None:
-            if self.fusion != "concat":
+            if not concat:
                 raise ValueError("forward_window(ces_targets=...) is built for fusion 'concat'")
-            hcat = h.transpose(0, 1).reshape(h.shape[1], -1)
-            att["loss"], att["risk"], hazards, survs, y = ops.fusion_head_loss_cat(hcat, self.fusion_layer, self.classifier,
+            att["loss"], att["risk"], hazards, survs, y = ops.fusion_head_loss_cat(h, self.fusion_layer, self.classifier,
                                                                                    *ces_targets)
             return hazards, survs, y, att
-        hazards, survs, y = self._fuse_and_head(h[0], h[1], h)
+        if concat:                              # h IS (B, [h_path | h_omic]): the pooling launch wrote it interleaved
+            hazards, survs, y = ops.fusion_head_cat(h, self.fusion_layer, self.classifier)
+        else:
+            hazards, survs, y = self._fuse_and_head(h[0], h[1])
         return hazards, survs, y, att
 
-    def _fuse_and_head(self, h_path, h_omic, stacked=None):
+    def _fuse_and_head(self, h_path, h_omic):
         """Fusion + classifier + survival head (models/mcat/mcat.py:119-138).  `concat` is one K6 call; the other fusion
         layers (row f4) run their own forward, then the classifier GEMM and the HIP head."""
         if self.fusion == "concat":
-            if stacked is not None:
-                hcat = stacked.transpose(0, 1).reshape(stacked.shape[1], -1)   # (B, [h_path | h_omic]): one copy each way
-                return ops.fusion_head_cat(hcat, self.fusion_layer, self.classifier)
             return ops.fusion_head(h_path, h_omic, self.fusion_layer, self.classifier)
         fused = self.fusion_layer(h_path, h_omic)
         return ops.survival_head(ops.linear(fused, self.classifier.weight, self.classifier.bias))

@@ -659,23 +659,23 @@ class GatedPoolFn(torch.autograd.Function):
     """K5: gated attention-MIL scorer + softmax pooling + rho, one C-ABI call each way."""
 
     @staticmethod
-    def forward(ctx, x, geom, head_p, rho_p, *params):
+    def forward(ctx, x, geom, head_p, rho_p, interleave, *params):
         lib = L.lib()
         ctx.set_materialize_grads(False)
         branches, n_slides, Lr, d = geom
         bt = branches * n_slides
         x = x.contiguous()
         scores = torch.empty(bt * Lr, device=x.device, dtype=torch.float32)
-        h = torch.empty(bt, d, device=x.device, dtype=torch.float32)
+        h = torch.empty((n_slides, branches * d) if interleave else (bt, d), device=x.device, dtype=torch.float32)
         saved = torch.empty(lib.mpo_gated_pool_saved_floats(bt, Lr, d), device=x.device, dtype=torch.float32)
         seed, off = _reserve(lib.mpo_gated_pool_rng_span(bt, Lr, d)) if (head_p > 0 or rho_p > 0) else (0, 0)
         pa = L.ptr_array(params)
         L.check(lib.mpo_gated_pool_forward(L.ptr(x), branches, n_slides, Lr, d, pa, float(head_p), float(rho_p), seed, off,
-                                           _epoch(), L.ptr(scores), L.ptr(h), L.ptr(saved), L.stream_of(x)),
+                                           _epoch(), L.ptr(scores), L.ptr(h), int(interleave), L.ptr(saved), L.stream_of(x)),
                 "mpo_gated_pool_forward")
         ctx.save_for_backward(x, saved, h, *params)
         ctx.param_refs = params
-        ctx.geom, ctx.drop = geom, (float(head_p), float(rho_p))
+        ctx.geom, ctx.drop, ctx.interleave = geom, (float(head_p), float(rho_p)), bool(interleave)
         return scores, h
 
     @staticmethod
@@ -693,9 +693,9 @@ class GatedPoolFn(torch.autograd.Function):
         dh = dh.contiguous()
         d_sc = d_scores.contiguous() if d_scores is not None else None
         L.check(lib.mpo_gated_pool_backward(
-            L.ptr(x), branches, n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h), L.ptr(dh), L.ptr(d_sc), L.ptr(dx), ga,
-            L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_gated_pool_backward")
-        return (dx, None, None, None, *grads)
+            L.ptr(x), branches, n_slides, Lr, d, pa, head_p, rho_p, L.ptr(saved), L.ptr(h), L.ptr(dh), int(ctx.interleave),
+            L.ptr(d_sc), L.ptr(dx), ga, L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_gated_pool_backward")
+        return (dx, None, None, None, None, *grads)
 
 
 def gated_pool(tokens, head, rho, training: bool):
@@ -715,8 +715,9 @@ def gated_pool_branches(tokens, heads, rhos, training: bool):
     return list(zip(sc.unbind(0), h.unbind(0)))
 
 
-def gated_pool_stacked(tokens, heads, rhos, training: bool):
-    """tokens (branches, B, L, d) -> raw scores (branches, B, 1, L), pooled embeddings (branches, B, d)."""
+def gated_pool_stacked(tokens, heads, rhos, training: bool, interleave: bool = False):
+    """tokens (branches, B, L, d) -> raw scores (branches, B, 1, L), pooled embeddings (branches, B, d) -- or, with
+    interleave, (B, branches * d): row b = [h_branch0 | h_branch1 | ...], the concatenation ConcatFusion reads."""
     nb, b, l, d = tokens.shape
     params = []
     for head, rho in zip(heads, rhos):
@@ -727,8 +728,8 @@ def gated_pool_stacked(tokens, heads, rhos, training: bool):
     if len(heads) != nb or len(rhos) != nb or len({(h.drop_p, r[2].p) for h, r in zip(heads, rhos)}) != 1:
         raise ValueError("branch-batched pooling needs one head + rho per branch with identical dropout rates")
     scores, h = GatedPoolFn.apply(tokens.reshape(nb * b * l, d), (nb, b, l, d), heads[0].drop_p if training else 0.0,
-                                  rhos[0][2].p if training else 0.0, *params)
-    return scores.view(nb, b, 1, l), h.view(nb, b, d)
+                                  rhos[0][2].p if training else 0.0, bool(interleave), *params)
+    return scores.view(nb, b, 1, l), (h if interleave else h.view(nb, b, d))
 
 
 class OmicSnnFn(torch.autograd.Function):

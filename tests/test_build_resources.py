@@ -44,7 +44,7 @@ def test_no_unexpected_scratch(usage):
 
 def test_headline_kernels_are_register_resident(usage):
     """The kernels the bench line is made of (E=256, bf16 bag) must have no scratch and no spills at all."""
-    hot = ["coattn_fwd_partial_kernelILi256ELb0", "coattn_bwd_kernelILi256ELb0", "bag_rowdot_gated_exact_kernelILi256E", "patch_coattn_fwd_kernel",
+    hot = ["coattn_fwd_partial_kernelILi256ELb0", "coattn_bwd_kernelILi256ELb0", "bag_rowdot_gated_exact_kernelILi256E", "patch_coattn_fwd_kernel", "patch_wgrad_kernel",
            "bag_colacc_gated_kernelILi256ELb1", "bag_outer_gated_kernelILi256ELb1", "gemm_f32_direct_kernelILi4",
            "gemm_f32_direct_kernelILi8"]
     for h in hot:

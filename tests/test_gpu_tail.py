@@ -271,6 +271,35 @@ def test_fused_head_and_loss_launch_equals_the_separate_launches(dev):
         torch.autograd.grad(per2, [h2], grad_outputs=w.clone())
 
 
+def test_interleaved_pool_output_is_the_concatenation(dev):
+    """gated_pool_stacked(interleave=True) writes h as (B, [branch 0 | branch 1]) -- the row ConcatFusion reads -- and
+    takes its gradient in that layout: values and every gradient equal the (branches, B, d) form."""
+    torch.manual_seed(3)
+    b, l, d = 5, 6, C.E
+    heads = [AttentionNetGated(n_classes=1, input_dim=d, hidden_dim=d).to(dev).eval() for _ in range(2)]
+    rhos = [nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Dropout(0.25)).to(dev).eval() for _ in range(2)]
+    tokens = torch.randn(2, b, l, d, device=dev)
+    probe = torch.randn(b, 2 * d, device=dev)
+    params = [p for m in heads + rhos for p in m.parameters()]
+
+    t0 = tokens.clone().requires_grad_(True)
+    sc0, h0 = ops.gated_pool_stacked(t0, heads, rhos, False)
+    g0 = torch.autograd.grad((h0.transpose(0, 1).reshape(b, -1) * probe).sum() + sc0.sum(), [t0] + params)
+    t1 = tokens.clone().requires_grad_(True)
+    sc1, h1 = ops.gated_pool_stacked(t1, heads, rhos, False, interleave=True)
+    assert h1.shape == (b, 2 * d)
+    assert torch.equal(h1, h0.transpose(0, 1).reshape(b, -1)) and torch.equal(sc1, sc0)
+    g1 = torch.autograd.grad((h1 * probe).sum() + sc1.sum(), [t1] + params)
+    for a, r in zip(g1, g0):
+        torch.testing.assert_close(a, r, rtol=1e-6, atol=1e-7)
+    # training: dropout on the interleaved rows at the configured rate, zeros where dropped, kept values scaled
+    for m in heads + rhos:
+        m.train()
+    _, ht = ops.gated_pool_stacked(tokens, heads, rhos, True, interleave=True)
+    dropped = float((ht == 0).float().mean())
+    assert 0.5 < dropped < 0.75                      # relu zeros (~1/2) plus a quarter of the rest
+
+
 def test_step_counters_bump_is_one_launch_for_both(dev):
     e = torch.tensor([41], dtype=torch.int64, device=dev)
     t = torch.tensor([6], dtype=torch.int32, device=dev)
