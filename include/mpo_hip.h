@@ -157,6 +157,11 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
                        const int32_t* step_dev /* nullable: device-resident step count, overrides `step` */,
                        mpo_stream_t stream);
 
+/* Verification hook (tests): the 6 x d token-tail products run a branch-free GEMM body when the product is regular
+ * (whole 16 x 16 tiles, K % 64 == 0, aligned operands, a gate known at compile time) and a general body otherwise; the two
+ * are bit-identical.  enabled = 0 sends everything through the general body.  Returns the previous setting (default 1). */
+int mpo_set_gemm_fast_path(int enabled);
+
 /* rng_epoch += 1 and adam_step += 1 (either may be NULL) in one launch: the per-step device counters of a captured
  * training step (dropout epoch of every mpo_*_forward, step count of mpo_adam_step_flat). */
 int mpo_step_counters_bump(uint64_t* rng_epoch, int32_t* adam_step, mpo_stream_t stream);

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "mpo_fusion_head_loss_forward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P, c_float, c_float] + [_P] * 6 + [_P]),
     "mpo_fusion_head_loss_backward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P] + [_P, c_size_t, _P]),
     "mpo_step_counters_bump": (c_int, [_P, _P, _P]),
+    "mpo_set_gemm_fast_path": (c_int, [c_int]),
     "mpo_omic_snn_saved_floats": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_workspace_bytes": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_rng_span": (c_uint64, [c_int] * 3),

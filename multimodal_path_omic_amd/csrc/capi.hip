@@ -553,6 +553,10 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
                                 step < 1 ? 1 : step, step_dev, stream);
 }
 
+// Verification hook: the small-row GEMMs have a branch-free body for regular products and a general body; both must
+// give the same bits.  enabled = 0 routes every product through the general body.  Returns the previous setting.
+int mpo_set_gemm_fast_path(int enabled) { return mpo_gemm_fast_path(enabled); }
+
 // The two device-resident per-step counters of a captured training step, bumped by one launch.
 int mpo_step_counters_bump(uint64_t* rng_epoch, int32_t* adam_step, mpo_stream_t stream) {
     MPO_CHECK(rng_epoch || adam_step, "step counters: nothing to bump");

@@ -26,19 +26,49 @@ void mpo_direct_single_nb4(const GemmArgs& g, int layout, dim3 grid, hipStream_t
 void mpo_direct_single_nb8(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream);
 void mpo_direct_group_nb4(const GemmGroup& grp, dim3 grid, hipStream_t stream);
 void mpo_direct_group_nb8(const GemmGroup& grp, dim3 grid, hipStream_t stream);
+void mpo_fast_group(const GemmGroup& grp, int gate_classes, int nbmax, dim3 grid, hipStream_t stream);
+void mpo_fast_single(const GemmArgs& g, int layout, int gate_classes, int nbmax, dim3 grid, hipStream_t stream);
 namespace {
 inline int direct_nbmax(int k) { return k <= 256 ? 4 : DMAXB; }
+// A product the branch-free body (gemm_f32_fast.h) can run: whole tiles, whole k-blocks per wave, vector-loadable
+// operands, a gate it knows at compile time.  Everything else goes through the general body.
+bool g_fast_path = true;                   // mpo_set_gemm_fast_path(): verification hook, on in production
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// -> gate class of the member (0 none, 1 value gate, 2 regenerated dropout), or -1: not for the fast body
+inline int fast_class(const GemmArgs& g) {
+    if (!g_fast_path) return -1;
+    if (g.M <= 0 || g.N <= 0 || (g.M & 15) || (g.N & 15) || g.K < 64 || (g.K & 63)) return -1;
+    if ((g.lda & 3) || (g.ldb & 3) || !aligned16(g.A) || !aligned16(g.B)) return -1;
+    switch (g.gate_mode) {
+        case MPO_GATE_NONE: return 0;
+        case MPO_GATE_RNG: return 2;
+        case MPO_GATE_RELU: case MPO_GATE_ELU: case MPO_GATE_TANH: case MPO_GATE_SIGMOID: case MPO_GATE_MUL:
+            return (g.gate != nullptr && aligned16(g.gate)) ? 1 : -1;
+        default: return -1;
+    }
+}
 void launch_direct_single(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream) {
+    const int fc = fast_class(g);
+    if (fc >= 0) { mpo_fast_single(g, layout, fc, direct_nbmax(g.K), grid, stream); return; }
     if (direct_nbmax(g.K) == 4) mpo_direct_single_nb4(g, layout, grid, stream);
     else mpo_direct_single_nb8(g, layout, grid, stream);
 }
 void launch_direct_group(const GemmGroup& grp, dim3 grid, hipStream_t stream) {
-    int kmax = 0;
-    for (int i = 0; i < grp.n; ++i) kmax = grp.g[i].K > kmax ? grp.g[i].K : kmax;
+    int kmax = 0, classes = 0;                                    // classes: bit c set when a member has gate class c
+    bool fast = true;
+    for (int i = 0; i < grp.n; ++i) {
+        kmax = grp.g[i].K > kmax ? grp.g[i].K : kmax;
+        const int fc = fast_class(grp.g[i]);
+        fast = fast && fc >= 0;
+        if (fc > 0) classes |= 1 << fc;
+    }
+    fast = fast && classes != ((1 << 1) | (1 << 2));              // value gates and regenerated dropout in one launch: general body
     // a launch that fills the chip several times over is throughput-bound: the 4-block variant's smaller register
-    // footprint (4 instead of 2 workgroups per CU) then beats having all of K in flight at once
+    // footprint (more workgroups per CU) then beats having all of K in flight at once
     const size_t wgs = (size_t)grid.x * grid.y * grid.z;
-    if (wgs > 1024 || direct_nbmax(kmax) == 4) mpo_direct_group_nb4(grp, grid, stream);
+    const int nb = (wgs > 1024 || direct_nbmax(kmax) == 4) ? 4 : DMAXB;
+    if (fast) { mpo_fast_group(grp, (classes >> 2) ? 2 : 1, nb, grid, stream); return; }
+    if (nb == 4) mpo_direct_group_nb4(grp, grid, stream);
     else mpo_direct_group_nb8(grp, grid, stream);
 }
 
@@ -63,6 +93,12 @@ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, 
 }
 
 }  // namespace
+
+int mpo_gemm_fast_path(int enabled) {
+    const int was = g_fast_path ? 1 : 0;
+    g_fast_path = enabled != 0;
+    return was;
+}
 
 int mpo_launch_gemm(const GemmArgs& g, int a_kc, int b_kc, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0) return 0;

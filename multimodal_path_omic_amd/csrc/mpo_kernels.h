@@ -156,6 +156,7 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
                           const float* ctx, const float* a_map, const float* da_map,
                           void* dbag, float* part_dqk, float* part_colsum /* nullable [parts][E] */, int n_q, const BagPlan& plan,
                           float relu_gate, hipStream_t stream);
+int mpo_gemm_fast_path(int enabled);   // gemm_f32.hip: returns the previous setting
 // dW_H = g^T X of the patch layer, hand-written (patch_wgrad.hip): part = mpo_patch_wgrad_partial_floats() floats
 size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim);
 int mpo_launch_patch_wgrad(const void* g_bf16, const void* x_bf16, int total_rows, int embed, int patch_dim, float* part,

@@ -14,8 +14,23 @@ import torch
 import torch.distributed as dist
 
 
+SLICE_ALIGN = 64        # elements: every parameter's slice starts on a 256-byte boundary of the flat buffers
+
+
+def _aligned_offsets(params):
+    """Start offset of every parameter in the flat buffers and their total length.  Slices are 256-byte aligned: the
+    GEMM kernels read weights with 16-byte loads, and one 1-element bias (attention_c.bias) packed tight would leave
+    every parameter behind it 4-byte aligned, i.e. on the general (guarded) GEMM body."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + SLICE_ALIGN - 1) // SLICE_ALIGN * SLICE_ALIGN
+    return offs, off
+
+
 class FlatGradBucket:
-    """One contiguous fp32 gradient buffer; every parameter owns a slice (`p._mpo_grad_view`).
+    """One contiguous fp32 gradient buffer; every parameter owns a slice (`p._mpo_grad_view`, 256-byte aligned,
+    `offsets[i]`; the padding between slices stays zero).
 
     Per window:  begin() -> forward/backward -> finish().  begin() unsets every `p.grad`, so the HIP
     backward entries write their parameter gradients straight into the slices (ops.grad_out) and autograd
@@ -25,14 +40,12 @@ class FlatGradBucket:
 
     def __init__(self, params: Sequence[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        self.offsets, n = _aligned_offsets(self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             p._mpo_grad_view = self.flat[off:off + p.numel()].view_as(p)
             p.grad = p._mpo_grad_view.view(p.shape)
-            off += p.numel()
 
     def begin(self):
         for p in self.params:
@@ -99,13 +112,11 @@ class FlatAdam:
 
     def __init__(self, bucket: FlatGradBucket, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.bucket, self.lr, self.betas, self.eps, self.wd = bucket, lr, betas, eps, weight_decay
-        self.flat_p = torch.empty_like(bucket.flat)
-        off = 0
-        for p in bucket.params:
+        self.flat_p = torch.zeros_like(bucket.flat)
+        for p, off in zip(bucket.params, bucket.offsets):
             sl = self.flat_p[off:off + p.numel()].view_as(p)
             sl.copy_(p.data)
             p.data = sl
-            off += p.numel()
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=self.flat_p.device)   # step count, device-resident

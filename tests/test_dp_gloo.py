@@ -82,10 +82,8 @@ def test_bucket_views_alias_param_grads():
     _loss(model, torch.ones(3, 8)).backward()
     bucket.finish()                                               # stock-torch gradients are copied into the slices
     assert bucket.flat.abs().sum() > 0
-    off = 0
-    for p in model.parameters():
-        assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
-        off += p.numel()
+    for p, off in zip(model.parameters(), bucket.offsets):       # slices in parameter order, each 256-byte aligned
+        assert p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off and off % 64 == 0
     ref = bucket.flat.clone()
     _loss(model, torch.ones(3, 8)).backward()                     # a second backward accumulates in place
     torch.testing.assert_close(bucket.flat, 2 * ref)
@@ -143,13 +141,16 @@ def test_split_exchange_on_real_parameter_layout(tmp_path):
     mp.spawn(_real_worker, args=(world, port, out), nprocs=world, join=True)
     got = torch.load(out, weights_only=True)
     model = _real_model()
-    n = sum(p.numel() for p in model.parameters())
+    bucket = FlatGradBucket(list(model.parameters()))            # (same layout as in the workers: slices 256-byte aligned)
+    n = bucket.flat.numel()
+    assert n == got["flat"].numel() >= sum(p.numel() for p in model.parameters())
     want = sum(_synthetic_grads(n, r) for r in range(world)) / world
     torch.testing.assert_close(got["flat"], want, rtol=1e-6, atol=1e-7)
     assert got["head"] == model.H[0].weight.numel() == 1024 * 128
     # parameter .grad tensors ARE the bucket slices (first and last parameter of the model)
     torch.testing.assert_close(got["grad_H"].flatten(), want[:got["head"]])
-    torch.testing.assert_close(got["grad_cls"].flatten(), want[-model.classifier.bias.numel():])
+    last = bucket.offsets[-1]
+    torch.testing.assert_close(got["grad_cls"].flatten(), want[last:last + model.classifier.bias.numel()])
 
 
 def test_flat_adam_repoints_parameters_and_keeps_state_dict():
@@ -162,11 +163,9 @@ def test_flat_adam_repoints_parameters_and_keeps_state_dict():
     assert list(before) == list(after)
     for k in before:
         torch.testing.assert_close(before[k], after[k], rtol=0, atol=0)
-    off = 0
-    for p in model.parameters():                          # every parameter is a view of the flat buffer, in bucket order
-        assert p.data_ptr() == opt.flat_p.data_ptr() + 4 * off
-        off += p.numel()
-    assert off == opt.flat_p.numel() == bucket.flat.numel()
+    for p, off in zip(model.parameters(), bucket.offsets):    # every parameter is a view of the flat buffer, in bucket order
+        assert p.data_ptr() == opt.flat_p.data_ptr() + 4 * off and off % 64 == 0
+    assert opt.flat_p.numel() == bucket.flat.numel() >= sum(p.numel() for p in model.parameters())
     opt.flat_p.add_(1.0)                                  # an update of the flat buffer IS an update of the model
     torch.testing.assert_close(model.classifier.bias.detach(), before["classifier.bias"] + 1.0)
     with pytest.raises(RuntimeError):                     # the update kernel is HIP: no CPU fallback

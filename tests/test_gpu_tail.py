@@ -300,6 +300,41 @@ def test_interleaved_pool_output_is_the_concatenation(dev):
     assert 0.5 < dropped < 0.75                      # relu zeros (~1/2) plus a quarter of the rest
 
 
+def test_fast_gemm_body_equals_the_general_body(dev):
+    """The branch-free GEMM body (regular products: every set-Transformer / pooling / fusion product of the model) against
+    the general body through a whole training-mode forward + backward of the branch-batched encoder and pooling head:
+    dropout epilogues, ReLU / tanh / sigmoid value gates and regenerated-dropout gates, dx and dW layouts.  Same
+    products in the same order and the same random streams: equal up to how the compiler contracts multiply-adds
+    (bias-gradient sums differ in the last bit), far below any parity tolerance -- a wrong mask or index would not be."""
+    from multimodal_path_omic_amd import _lib as L
+    torch.manual_seed(5)
+    b, l, d = 32, 6, C.E
+    enc = [make_set_transformer(d, dropout=0.25).to(dev).train() for _ in range(2)]
+    heads = [AttentionNetGated(n_classes=1, input_dim=d, hidden_dim=d).to(dev).train() for _ in range(2)]
+    rhos = [nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Dropout(0.25)).to(dev).train() for _ in range(2)]
+    x = torch.randn(2, b, l, d, device=dev)
+    probe = torch.randn(b, 2 * d, device=dev)
+    params = [p for m in enc + heads + rhos for p in m.parameters()]
+
+    def run():
+        ops._rng_calls = 1000                                   # same Philox streams in both runs
+        t = x.clone().requires_grad_(True)
+        tok = ops.encoder_stacked(t, [list(e.layers) for e in enc], True)
+        sc, h = ops.gated_pool_stacked(tok, heads, rhos, True, interleave=True)
+        g = torch.autograd.grad((h * probe).sum() + sc.sum(), [t] + params)
+        return [h.detach().clone(), sc.detach().clone()] + [gi.clone() for gi in g]
+
+    fast = run()
+    was = L.lib().mpo_set_gemm_fast_path(0)
+    try:
+        general = run()
+    finally:
+        L.lib().mpo_set_gemm_fast_path(was)
+    assert was == 1
+    for i, (a, r) in enumerate(zip(fast, general)):
+        torch.testing.assert_close(a, r, rtol=1e-5, atol=1e-6 * float(r.abs().max()), msg=lambda m, i=i: f"tensor {i}: {m}")
+
+
 def test_step_counters_bump_is_one_launch_for_both(dev):
     e = torch.tensor([41], dtype=torch.int64, device=dev)
     t = torch.tensor([6], dtype=torch.int32, device=dev)
