@@ -34,16 +34,18 @@ inline int direct_nbmax(int k) { return k <= 256 ? 4 : DMAXB; }
 // operands, a gate it knows at compile time.  Everything else goes through the general body.
 bool g_fast_path = true;                   // mpo_set_gemm_fast_path(): verification hook, on in production
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-// -> gate class of the member (0 none, 1 value gate, 2 regenerated dropout), or -1: not for the fast body
+// -> gate class of the member (0 none, 1 value gate, 2 regenerated dropout, 3 AlphaDropout + ELU derivative), or -1: not
+// for the fast body
 inline int fast_class(const GemmArgs& g) {
     if (!g_fast_path) return -1;
-    if (g.M <= 0 || g.N <= 0 || (g.M & 15) || (g.N & 15) || g.K < 64 || (g.K & 63)) return -1;
+    if (g.M <= 0 || g.N <= 0 || (g.M & 15) || (g.N & 15) || g.K < 16 || (g.K & 15)) return -1;
     if ((g.lda & 3) || (g.ldb & 3) || !aligned16(g.A) || !aligned16(g.B)) return -1;
     switch (g.gate_mode) {
         case MPO_GATE_NONE: return 0;
         case MPO_GATE_RNG: return 2;
         case MPO_GATE_RELU: case MPO_GATE_ELU: case MPO_GATE_TANH: case MPO_GATE_SIGMOID: case MPO_GATE_MUL:
             return (g.gate != nullptr && aligned16(g.gate)) ? 1 : -1;
+        case MPO_GATE_ELU_ADROP: return (g.gate != nullptr && aligned16(g.gate)) ? 3 : -1;
         default: return -1;
     }
 }
@@ -62,12 +64,12 @@ void launch_direct_group(const GemmGroup& grp, dim3 grid, hipStream_t stream) {
         fast = fast && fc >= 0;
         if (fc > 0) classes |= 1 << fc;
     }
-    fast = fast && classes != ((1 << 1) | (1 << 2));              // value gates and regenerated dropout in one launch: general body
+    fast = fast && (classes & (classes - 1)) == 0;                // two gate classes in one launch: general body
     // a launch that fills the chip several times over is throughput-bound: the 4-block variant's smaller register
     // footprint (more workgroups per CU) then beats having all of K in flight at once
     const size_t wgs = (size_t)grid.x * grid.y * grid.z;
     const int nb = (wgs > 1024 || direct_nbmax(kmax) == 4) ? 4 : DMAXB;
-    if (fast) { mpo_fast_group(grp, (classes >> 2) ? 2 : 1, nb, grid, stream); return; }
+    if (fast) { mpo_fast_group(grp, classes >> 3 ? 3 : classes >> 2 ? 2 : 1, nb, grid, stream); return; }
     if (nb == 4) mpo_direct_group_nb4(grp, grid, stream);
     else mpo_direct_group_nb8(grp, grid, stream);
 }

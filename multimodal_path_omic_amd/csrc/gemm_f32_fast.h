@@ -4,13 +4,13 @@
 // and ~600 branches per layout, and a grouped launch carries four layouts -- the token tail's 35 GEMM launches per
 // window step spent most of their 8-19 us walking that code (instruction fetch, not loads or MFMAs: weights hot in L2
 // made them 10 % faster, no more).  Nearly all of those products are regular:
-//     M % 16 == 0, N % 16 == 0, K % 64 == 0, leading dimensions % 4 == 0, 16-byte aligned operands,
-//     gate one of {none, a value gate (ReLU / ELU / tanh / sigmoid derivative, multiply), plain dropout regenerated from Philox}.
+//     M % 16 == 0, N % 16 == 0, K % 16 == 0, leading dimensions % 4 == 0, 16-byte aligned operands,
+//     gate one of {none, a value gate (ReLU / ELU / tanh / sigmoid derivative, multiply), dropout regenerated from Philox,
+//     the AlphaDropout + ELU derivative of the omic SNNs (value and Philox word)}.
 // For those this body has no per-element predicate at all: whole-fragment float4 loads (or four strided scalars when k is
 // not the contiguous index), the gate class fixed at compile time, a k loop of full chunks plus one remainder chunk.
 // Arithmetic, summation order and random streams are those of the general body (results are bit-identical); launches
-// with an irregular member (the 256 -> 1 scorer, the 4-class classifier, the fusion layer's 32-row weight gradients,
-// AlphaDropout gates of the omic SNNs) keep using it.
+// with an irregular member (the 256 -> 1 scorer, the 4-class classifier) keep using it.
 #pragma once
 #include "gemm_f32_gate.h"
 
@@ -23,15 +23,7 @@ struct FastLds {
     float bsum[4][16];
 };
 
-// gate class of a launch member: 0 none, 1 value gate (no random numbers), 2 MPO_GATE_RNG
-__host__ __device__ inline int gate_class(int mode) {
-    switch (mode) {
-        case MPO_GATE_NONE: return 0;
-        case MPO_GATE_RELU: case MPO_GATE_ELU: case MPO_GATE_TANH: case MPO_GATE_SIGMOID: case MPO_GATE_MUL: return 1;
-        case MPO_GATE_RNG: return 2;
-        default: return 3;             // AlphaDropout derivative: general body
-    }
-}
+// gate class of a launch member: 0 none, 1 value gate (no random numbers), 2 MPO_GATE_RNG, 3 MPO_GATE_ELU_ADROP
 
 template <bool KC>
 __device__ __forceinline__ f32x4 fast_frag(const float* __restrict__ p, int ld, int mn, int k0) {
@@ -56,7 +48,7 @@ struct FastCtx {
             const int k0 = kbase + 16 * u + 4 * kq;
             a[u] = fast_frag<A_KC>(g.A, g.lda, m, k0);
             b[u] = fast_frag<B_KC>(g.B, g.ldb, n, k0);
-            if (GC == 1) gv[u] = fast_frag<A_KC>(gf.g, g.lda, m, k0);
+            if (GC == 1 || GC == 3) gv[u] = fast_frag<A_KC>(gf.g, g.lda, m, k0);
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -64,14 +56,14 @@ struct FastCtx {
             if (GC == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a[u][j] *= gf(gv[u][j], 0);
-            } else if (GC == 2) {
+            } else if (GC >= 2) {
                 if (A_KC) {
                     // element (m, k0 + j) has index m * lda + k0 + j; lda % 4 == 0 and k0 % 4 == 0: one counter per fragment
                     const uint64_t ctr = gf.off + (((size_t)m * g.lda + k0) >> 2);
                     const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
                     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) a[u][j] *= gf.with_word(0.f, w[j]);
+                    for (int j = 0; j < 4; ++j) a[u][j] *= gf.with_word(GC == 3 ? gv[u][j] : 0.f, w[j]);
                 } else {
                     // element (k0 + j, m) has index (k0 + j) * lda + m: the lanes of a quad (m = 4q .. 4q+3) share one
                     // counter per j; lane s of the quad draws j = s, four quad exchanges transpose the words
@@ -90,7 +82,7 @@ struct FastCtx {
                         for (int j = 0; j < 4; ++j) if (j == (lq ^ t)) w[j] = got;
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) a[u][j] *= gf.with_word(0.f, w[j]);
+                    for (int j = 0; j < 4; ++j) a[u][j] *= gf.with_word(GC == 3 ? gv[u][j] : 0.f, w[j]);
                 }
             }
             if (want_bsum) bsum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
@@ -127,14 +119,15 @@ __device__ __forceinline__ void gemm_f32_fast_body(const GemmArgs& g, FastLds& l
         e_keep = dropout_keep(g.drop_seed, doff, eo, g.drop_p, g.alpha_dropout ? 1.0f : 1.0f / (1.0f - g.drop_p));
     }
 
-    const int kw = g.K >> 2;                                    // K % 64 == 0: a multiple of 16 per wave
-    const int kbeg = wave * kw, nkb = kw >> 4;
+    const int kw = ((g.K + 63) >> 6) << 4;                      // k per wave, a multiple of 16 (as in the general body)
+    const int kbeg = wave * kw;
+    const int nkb = max(0, min(kw, g.K - kbeg)) >> 4;           // K % 16 == 0: whole blocks; wave-uniform
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     float bsum = 0.f;
     FastCtx<A_KC, B_KC, GC> cx{g, gf, m0 + i16, n0 + i16, kq, lane, want_bsum};
     int kb = 0;
     for (; kb + NBMAX <= nkb; kb += NBMAX) cx.template chunk<NBMAX>(kbeg + 16 * kb, acc0, acc1, bsum);
-    // remainder of the wave's k range: one chunk of 1 .. NBMAX-1 blocks (workgroup-uniform)
+    // remainder of the wave's k range: one chunk of 1 .. NBMAX-1 blocks (wave-uniform)
     const int rem = nkb - kb;
     if (rem >= 4) { cx.template chunk<4>(kbeg + 16 * kb, acc0, acc1, bsum); kb += 4; }
     switch (nkb - kb) {
@@ -166,8 +159,9 @@ __device__ __forceinline__ void gemm_f32_fast_body(const GemmArgs& g, FastLds& l
         g.bias_grad[m0 + tid] = (lds.bsum[0][tid] + lds.bsum[1][tid]) + (lds.bsum[2][tid] + lds.bsum[3][tid]);
 }
 
-// GCL: the gate classes a launch may contain besides "none" -- 1: value gates, 2: regenerated dropout.  (One kernel with
-// all three classes crosses a size at which the compiler copies the by-value GemmGroup into scratch.)
+// GCL: the gate class a launch may contain besides "none" -- 1: value gates, 2: regenerated dropout, 3: AlphaDropout + ELU
+// derivative.  (One kernel with several classes crosses a size at which the compiler copies the by-value GemmGroup
+// into scratch.)
 template <bool A_KC, bool B_KC, int GCL, int NBMAX>
 __device__ __forceinline__ void gemm_f32_fast_member(const GemmArgs& g, FastLds& lds) {
     if (g.gate_mode == MPO_GATE_NONE) gemm_f32_fast_body<A_KC, B_KC, 0, NBMAX>(g, lds);     // uniform over the workgroup

@@ -11,14 +11,17 @@ void launch(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream) {
         default: gemm_f32_fast_single_kernel<false, false, GCL, NB><<<grid, 256, 0, stream>>>(g); break;
     }
 }
+template <int GCL>
+void launch_nb(const GemmArgs& g, int layout, int nbmax, dim3 grid, hipStream_t stream) {
+    if (nbmax == 4) launch<GCL, 4>(g, layout, grid, stream);
+    else launch<GCL, 8>(g, layout, grid, stream);
+}
 }  // namespace
 
-void mpo_fast_single(const GemmArgs& g, int layout, int gate_classes, int nbmax, dim3 grid, hipStream_t stream) {
-    if (gate_classes <= 1) {
-        if (nbmax == 4) launch<1, 4>(g, layout, grid, stream);
-        else launch<1, 8>(g, layout, grid, stream);
-    } else {
-        if (nbmax == 4) launch<2, 4>(g, layout, grid, stream);
-        else launch<2, 8>(g, layout, grid, stream);
+void mpo_fast_single(const GemmArgs& g, int layout, int gate_class, int nbmax, dim3 grid, hipStream_t stream) {
+    switch (gate_class) {
+        case 3: launch_nb<3>(g, layout, nbmax, grid, stream); break;
+        case 2: launch_nb<2>(g, layout, nbmax, grid, stream); break;
+        default: launch_nb<1>(g, layout, nbmax, grid, stream); break;
     }
 }

@@ -314,15 +314,23 @@ def test_fast_gemm_body_equals_the_general_body(dev):
     rhos = [nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Dropout(0.25)).to(dev).train() for _ in range(2)]
     x = torch.randn(2, b, l, d, device=dev)
     probe = torch.randn(b, 2 * d, device=dev)
-    params = [p for m in enc + heads + rhos for p in m.parameters()]
+    # the omic SNNs (AlphaDropout + ELU derivative gates, 32-row weight gradients) and the fusion MLP (K = 32 products)
+    G = nn.ModuleList([nn.Sequential(nn.Sequential(nn.Linear(d, d), nn.ELU(), nn.AlphaDropout(0.25)),
+                                     nn.Sequential(nn.Linear(d, d), nn.ELU(), nn.AlphaDropout(0.25))) for _ in range(l)]).to(dev).train()
+    fus = ConcatFusion(dims=[d, d], hidden_size=d, output_size=d).to(dev)
+    cls = nn.Linear(d, 4).to(dev)
+    omics = [torch.randn(b, d, device=dev) for _ in range(l)]
+    params = [p for m in enc + heads + rhos + [G, fus, cls] for p in m.parameters()]
 
     def run():
         ops._rng_calls = 1000                                   # same Philox streams in both runs
         t = x.clone().requires_grad_(True)
-        tok = ops.encoder_stacked(t, [list(e.layers) for e in enc], True)
+        g_bag = ops.omic_snn(omics, G, True)
+        tok = ops.encoder_stacked(t + torch.stack([g_bag, g_bag]), [list(e.layers) for e in enc], True)
         sc, h = ops.gated_pool_stacked(tok, heads, rhos, True, interleave=True)
-        g = torch.autograd.grad((h * probe).sum() + sc.sum(), [t] + params)
-        return [h.detach().clone(), sc.detach().clone()] + [gi.clone() for gi in g]
+        hz, sv, y = ops.fusion_head_cat(h, fus, cls)
+        g = torch.autograd.grad((h * probe).sum() + sc.sum() + (hz * sv).sum() + y[:, 0].sum(), [t] + params)
+        return [h.detach().clone(), sc.detach().clone(), hz.detach().clone()] + [gi.clone() for gi in g]
 
     fast = run()
     was = L.lib().mpo_set_gemm_fast_path(0)
