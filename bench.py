@@ -201,7 +201,7 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
                                                    L.ptr(qk2), L.ptr(part_ml), L.ptr(part_ctx), None, n_q, patches, plan,
                                                    stream.cuda_stream), "mpo_coattn_fwd_bagpass")
         alg_bytes = window * patches * E * esz
-        name = "bag_rowdot_gated_kernel<256,f32 key bag>" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
+        name = "bag_rowdot_gated_exact_kernel<256> (f32 key bag)" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
         tname = "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json"
         applies = window == 32 and patches == 15000 and (k2 or esz == 2)
     us, burst = _time_launches(dev, launch, reps)
