@@ -168,8 +168,10 @@ __device__ __forceinline__ void gemm_f32_fast_member(const GemmArgs& g, FastLds&
     else gemm_f32_fast_body<A_KC, B_KC, GCL, NBMAX>(g, lds);
 }
 
+// (the regenerated-dropout kernel at four blocks in flight fits 80 registers without spilling when asked to: six
+//  workgroups per CU instead of four, and its launches are the ones with 1 400 - 2 000 workgroups)
 template <int GCL, int NBMAX>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GCL == 2 && NBMAX == 4) ? 6 : 1, 8)))
 void gemm_f32_fast_group_kernel(GemmGroup grp) {
     __shared__ FastLds lds;
     const GemmArgs& g = grp.g[blockIdx.z];

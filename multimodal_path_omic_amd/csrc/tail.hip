@@ -103,17 +103,44 @@ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, co
 // qkv [B*T][3d] (q | k | v), H heads of hd = d / H.  One workgroup per slide, everything through LDS.
 constexpr int kMaxT = 16;
 
+// global -> LDS copy of n floats by the 256 threads of a workgroup: up to eight independent 16-byte loads per thread in
+// flight (a plain `for (i = tid; i < n; i += 256) dst[i] = src[i]` becomes load, wait, store, 18 times over: the 11 us of
+// the forward kernel and 14 us of the backward were mostly that chain)
+__device__ __forceinline__ void stage_to_lds(float* dst, const float* __restrict__ src, int n, int tid) {
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const int n4 = n >> 2;
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+        f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+        for (int base = 0; base < n4; base += 8 * 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = base + k * 256 + tid;
+                v[k] = s4[i < n4 ? i : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = base + k * 256 + tid;
+                if (i < n4) d4[i] = v[k];
+            }
+        }
+        for (int i = (n4 << 2) + tid; i < n; i += 256) dst[i] = src[i];
+    } else {
+        for (int i = tid; i < n; i += 256) dst[i] = src[i];
+    }
+}
+
 __global__ __launch_bounds__(256)
 void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ p_save /* [B][H][T][T] x2: p, p_post */,
                           int T, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset_,
                           const unsigned long long* epoch) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const unsigned long long offset = epoch_offset(offset_, epoch);
     float* sq = sm;                       // [T][3d]
     float* sp = sm + T * 3 * d;           // [H][T][T]
     const int b = blockIdx.x, hd = d / H, tid = threadIdx.x;
     const float scale = rsqrtf((float)hd);
-    for (int i = tid; i < T * 3 * d; i += 256) sq[i] = qkv[(size_t)b * T * 3 * d + i];
+    stage_to_lds(sq, qkv + (size_t)b * T * 3 * d, T * 3 * d, tid);
     __syncthreads();
     for (int it = tid; it < H * T * T; it += 256) {
         const int h = it / (T * T), i = (it / T) % T, j = it % T;
@@ -161,19 +188,21 @@ void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, 
 __global__ __launch_bounds__(256)
 void mha_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ p_save, const float* __restrict__ d_o,
                           float* __restrict__ dqkv, int T, int d, int H) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sq = sm;                       // [T][3d]
     float* sdo = sq + T * 3 * d;          // [T][d]
     float* sds = sdo + T * d;             // [H][T][T]  dS
+    float* sdp = sds + H * T * T;         // [H][T][T]  dP
+    float* spp = sdp + H * T * T;         // [2][H][T][T]  P, P after dropout (saved by the forward)
     const int b = blockIdx.x, hd = d / H, tid = threadIdx.x;
     const float scale = rsqrtf((float)hd);
-    for (int i = tid; i < T * 3 * d; i += 256) sq[i] = qkv[(size_t)b * T * 3 * d + i];
-    for (int i = tid; i < T * d; i += 256) sdo[i] = d_o[(size_t)b * T * d + i];
+    stage_to_lds(sq, qkv + (size_t)b * T * 3 * d, T * 3 * d, tid);
+    stage_to_lds(sdo, d_o + (size_t)b * T * d, T * d, tid);
+    stage_to_lds(spp, p_save + (size_t)b * 2 * H * T * T, 2 * H * T * T, tid);
     __syncthreads();
-    const float* pb = p_save + (size_t)b * 2 * H * T * T;
+    const float* pb = spp;
     const float* ppb = pb + H * T * T;
     // dP[h][i][j] = do[i] . v[j] over the head's columns: one thread per (h, i, j), bank-rotated as in the forward
-    float* sdp = sds + H * T * T;         // [H][T][T]
     for (int it = tid; it < H * T * T; it += 256) {
         const int h = it / (T * T), i = (it / T) % T, j = it % T;
         const float* vj = sq + j * 3 * d + 2 * d + h * hd;
@@ -554,7 +583,8 @@ int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, i
 int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float* d_o, float* dqkv, int B, int T, int d, int H,
                              hipStream_t s) {
     MPO_CHECK(T >= 1 && T <= kMaxT && d % H == 0, "set-transformer attention: T=%d (max %d), d=%d, heads=%d", T, kMaxT, d, H);
-    const size_t lds = ((size_t)T * 4 * d + (size_t)2 * H * T * T) * sizeof(float);
+    const size_t lds = ((size_t)T * 4 * d + (size_t)4 * H * T * T) * sizeof(float);
+    MPO_CHECK(lds <= 160 * 1024, "set-transformer attention backward: T=%d, d=%d needs %zu bytes of LDS", T, d, lds);
     mha_small_bwd_kernel<<<B, 256, lds, s>>>(qkv, p_save, d_o, dqkv, T, d, H);
     MPO_LAUNCH_CHECK();
     return 0;
