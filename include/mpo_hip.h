@@ -98,6 +98,14 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
                                   void* h_bag, float* out, float* attn_map /* nullable */, float* saved,
                                   const mpo_bag_plan* plan /* nullable */, void* workspace, size_t workspace_bytes,
                                   mpo_stream_t stream);
+/* The patch layer alone: h_bag [total_rows, embed] bf16 = dropout(relu(patches W^T + b)) (models/mcat/mcat.py:24-29,87), one
+ * pass of the fused kernel with its co-attention slices off (NaCAGaT needs H_bag for more than one product; MCAT outside
+ * the fused configuration).  Same dropout stream and realised rate as mpo_patch_coattn_mcat_forward. */
+size_t mpo_patch_fc_workspace_bytes(int embed, int patch_dim);
+int mpo_patch_fc_forward(const void* patches, const int32_t* cu_rows, int n_slides, int total_rows, int max_rows, int patch_dim,
+                         const float* patch_weight, const float* patch_bias, int embed, float drop_p, uint64_t seed,
+                         uint64_t offset, const uint64_t* rng_epoch, void* h_bag, const mpo_bag_plan* plan /* nullable */,
+                         void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 /* The fused bag pass alone (measurement): w_packed = embed * patch_dim bf16 values from mpo_pack_patch_weight (the weight
  * in the fragment order of the kernel's GEMM waves), qk2 [n_slides*n_q, embed]. */
 int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_packed, const float* bias, const int32_t* cu_rows, int n_slides,

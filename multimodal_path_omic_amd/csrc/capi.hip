@@ -213,6 +213,27 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
     return 0;
 }
 
+// The patch layer alone, H_bag = dropout(relu(X W_H^T + b_H)) (models/mcat/mcat.py:24-29,87), as ONE pass of the same
+// kernel with its co-attention slices switched off: for the models whose co-attention needs more than H_bag (NaCAGaT's
+// key projection) and for MCAT outside the fused configuration.  Workspace: the packed bf16 copy of the weight.
+size_t mpo_patch_fc_workspace_bytes(int embed, int patch_dim) { return (size_t)embed * patch_dim * 2 + 256; }
+int mpo_patch_fc_forward(const void* patches, const int32_t* cu_rows, int n_slides, int total_rows, int max_rows, int patch_dim,
+                         const float* patch_weight, const float* patch_bias, int embed, float drop_p, uint64_t seed,
+                         uint64_t offset, const uint64_t* rng_epoch, void* h_bag, const mpo_bag_plan* plan_, void* workspace,
+                         size_t workspace_bytes, mpo_stream_t stream) {
+    if (int rc = check_common(MPO_BF16, n_slides, total_rows, max_rows, 1, embed)) return rc;
+    MPO_CHECK(embed == 256 && patch_dim == 1024, "patch layer kernel is built for 1024 -> 256 (got %d -> %d)", patch_dim, embed);
+    const BagPlan plan = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(plan, n_slides)) return rc;
+    Arena ws(workspace, workspace_bytes);
+    float* w_bf16 = ws.floats((size_t)embed * patch_dim / 2);
+    MPO_CHECK(w_bf16, "patch layer: workspace too small (%zu bytes)", workspace_bytes);
+    int rc;
+    if ((rc = mpo_launch_pack_patch_weight(patch_weight, w_bf16, embed, patch_dim, stream))) return rc;
+    return mpo_launch_patch_coattn_fwd(patches, w_bf16, patch_bias, cu_rows, nullptr, h_bag, nullptr, nullptr, nullptr, 0, drop_p,
+                                       seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), plan, stream);
+}
+
 // the fused bag pass alone (bench.py's roofline leg, profiling workloads)
 int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_packed, const float* bias, const int32_t* cu_rows, int n_slides,
                                  const float* qk2, void* h_bag, float* part_ml, float* part_ctx, int n_q, int max_rows,

@@ -208,13 +208,14 @@ void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows
     const int b = wg.b, row_begin = wg.row_begin, m_rows = wg.m_rows, r0 = wg.r0, r1 = wg.r1;
     const int nblocks = r1 > r0 ? (r1 - r0 + BM - 1) / BM : 0;
     const int n_stages = nblocks * KSTEPS;
+    const bool tail_on = qk2 != nullptr;      // NULL: patch layer only (H_bag is the only output); same barriers, no co-attention slices
 
     // ---- prologue: bias and the query fragments (three bf16 terms, compact [term][k-step][group][slot]) into LDS
     {
         float* lb = reinterpret_cast<float*>(lds + OFF_BIAS);
         if (tid < PE) lb[tid] = bias[tid];
-        const float* qrow = qk2 + (size_t)b * n_q * PE;
-        for (int e = tid; e < 8 * 4 * QCAP; e += NTHREADS) {
+        const float* qrow = tail_on ? qk2 + (size_t)b * n_q * PE : nullptr;
+        for (int e = tid; tail_on && e < 8 * 4 * QCAP; e += NTHREADS) {
             const int slot = e % QCAP, sg = e / QCAP;             // sg = 4 s + g
             bf16x8 t0, t1, t2;
 #pragma unroll
@@ -430,7 +431,7 @@ void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows
                     copy_out_rows(lds + OFF_IMG, hprev, BM, 32 * h + 4 * k, lane);
                     copy_out_rows(lds + OFF_IMG, hprev, BM, 32 * h + 4 * k + 2, lane);
                 }
-                if (rows_prev > 0 && k < 2 * TAIL_STEPS) {        // one slice of the previous block's co-attention (k is wave-uniform)
+                if (tail_on && rows_prev > 0 && k < 2 * TAIL_STEPS) {        // one slice of the previous block's co-attention (k is wave-uniform)
                     int el = lane;                                // (opaque per slice: its LDS addresses are computed here)
                     asm volatile("" : "+v"(el));
 #define MPO_TAIL_CASE(SL) if (k == SL) tail_step<SL>(st, img64, rows_prev, qf, qslot, dhalf, s_prev, q_live, el);
@@ -444,7 +445,7 @@ void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows
         if (nblocks > 0) {                                        // the last block's image: nobody rewrites it
             const int rows_last = min(BM, r1 - (r0 + (nblocks - 1) * BM)) - 64 * pair;
             float* s_last = s_row ? s_row + r0 + (nblocks - 1) * BM + 64 * pair : nullptr;
-            if (rows_last > 0) tail_steps_from<0>(st, img64, rows_last, qf, qslot, dhalf, s_last, q_live, lane);
+            if (tail_on && rows_last > 0) tail_steps_from<0>(st, img64, rows_last, qf, qslot, dhalf, s_last, q_live, lane);
             const int rb = r0 + (nblocks - 1) * BM;
             char* hlast = reinterpret_cast<char*>(h_out) + ((size_t)row_begin + rb) * IMG_ROWB;
             for (int i = 0; i < 16; ++i) copy_out_rows(lds + OFF_IMG, hlast, min(BM, r1 - rb), 32 * h + 2 * i, lane);
@@ -466,6 +467,7 @@ void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows
     }
 
     // ---- merge into ONE partial per workgroup (all threads)
+    if (!tail_on) return;
     const float* ml = reinterpret_cast<const float*>(lds + OFF_ML);
     for (int idx = tid; idx < n_q * PE; idx += NTHREADS) {
         const int qq = idx / PE;
@@ -528,7 +530,8 @@ int mpo_launch_patch_coattn_fwd(const void* x, const void* w_bf16, const float* 
                                 void* h_out, float* part_ml, float* part_ctx, float* s_out, int n_q, float drop_p,
                                 unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
                                 const BagPlan& plan, hipStream_t stream) {
-    MPO_CHECK(n_q >= 1 && n_q <= QCAP - 1, "fused patch layer + co-attention: 1..%d queries (got %d)", QCAP - 1, n_q);
+    MPO_CHECK(qk2 == nullptr || (n_q >= 1 && n_q <= QCAP - 1), "fused patch layer + co-attention: 1..%d queries (got %d)", QCAP - 1, n_q);
+    MPO_CHECK(qk2 != nullptr || (part_ml == nullptr && part_ctx == nullptr && s_out == nullptr), "patch layer only: no co-attention outputs");
     MPO_CHECK(drop_p >= 0.f && drop_p < 1.f, "patch-layer dropout p must be in [0,1) (got %f)", (double)drop_p);
 patch_coattn_fwd_kernel<<<plan_grid(plan), NTHREADS, 0, stream>>>(
         reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(w_bf16), bias, cu, qk2,

@@ -70,7 +70,7 @@ class _FusionModelBase(nn.Module):
         lin = self.H[0]
         p = self.H[2].p if self.training else 0.0
         if x.dtype == torch.bfloat16:
-            h = ops.patch_fc(x, lin.weight, lin.bias, p, pre_gated_grad=self._fused_bag_gate)
+            h = ops.patch_fc(x, lin.weight, lin.bias, p, pre_gated_grad=self._fused_bag_gate, batch=bags)
         else:
             h = F.dropout(torch.relu(F.linear(x.float(), lin.weight, lin.bias)), p, self.training)
         return bags.with_data(h)
@@ -159,7 +159,7 @@ class MultimodalCoAttentionTransformer(_FusionModelBase):
     def _co_attend(self, g_bag, h_bags, inference):
         gate = 0.0
         if h_bags.data.dtype == torch.bfloat16:
-            gate = 1.0 / (1.0 - self.H[2].p) if self.training else 1.0
+            gate = getattr(h_bags.data, "_mpo_keep_scale", 1.0 / (1.0 - self.H[2].p)) if self.training else 1.0
         return self.co_attention.forward_window(g_bag, h_bags, need_weights=inference, bag_relu_gate=gate)
 
     def _token_pair(self, bags: BagBatch, omics):
@@ -205,7 +205,7 @@ class NarrowContextualAttentionGateTransformer(_FusionModelBase):
     def _co_attend(self, g_bag, h_bags, inference):
         gate = 0.0
         if h_bags.data.dtype == torch.bfloat16:
-            gate = 1.0 / (1.0 - self.H[2].p) if self.training else 1.0
+            gate = getattr(h_bags.data, "_mpo_keep_scale", 1.0 / (1.0 - self.H[2].p)) if self.training else 1.0
         return self.co_attention.forward_window(g_bag, h_bags, bag_relu_gate=gate)
 
     def forward(self, wsi, omics):

@@ -290,12 +290,23 @@ class PatchFcFn(torch.autograd.Function):
     and summed.  X never needs a gradient (it is data)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, drop_p: float, pre_gated_grad: bool):
+    def forward(ctx, x, weight, bias, drop_p: float, pre_gated_grad: bool, batch=None):
         lib = L.lib()
-        h = torch.mm(x, weight.to(torch.bfloat16).t())
-        seed, off = _reserve(h.numel() // 8 + 2) if drop_p > 0 else (0, 0)
-        L.check(lib.mpo_patch_epilogue_forward(L.ptr(h), L.ptr(bias), h.shape[0], h.shape[1], float(drop_p), seed, off,
-                                               _epoch(), L.stream_of(h)), "mpo_patch_epilogue_forward")
+        if batch is not None and patch_fc_kernel_supported(x, weight):
+            # one pass of the fused kernel with its co-attention slices off (no library GEMM, H_bag rounded once)
+            h = torch.empty(x.shape[0], weight.shape[0], device=x.device, dtype=torch.bfloat16)
+            seed, off = _reserve(h.numel() // 16 + 2) if drop_p > 0 else (0, 0)
+            ws = _workspace(lib.mpo_patch_fc_workspace_bytes(weight.shape[0], weight.shape[1]), x.device)
+            L.check(lib.mpo_patch_fc_forward(L.ptr(x), L.ptr(batch.cu), batch.n_slides, batch.total_rows, batch.max_rows,
+                                             x.shape[1], L.ptr(weight), L.ptr(bias), weight.shape[0], float(drop_p), seed, off,
+                                             _epoch(), L.ptr(h), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(x)),
+                    "mpo_patch_fc_forward")
+            drop_p = _realised_drop(drop_p) if drop_p > 0 else 0.0
+        else:
+            h = torch.mm(x, weight.to(torch.bfloat16).t())
+            seed, off = _reserve(h.numel() // 8 + 2) if drop_p > 0 else (0, 0)
+            L.check(lib.mpo_patch_epilogue_forward(L.ptr(h), L.ptr(bias), h.shape[0], h.shape[1], float(drop_p), seed, off,
+                                                   _epoch(), L.stream_of(h)), "mpo_patch_epilogue_forward")
         ctx.save_for_backward(x, h)
         ctx.param_refs = (weight, bias)
         ctx.drop_p, ctx.pre_gated = float(drop_p), bool(pre_gated_grad)
@@ -330,7 +341,7 @@ class PatchFcFn(torch.autograd.Function):
             _deferred_patch.append((g, x, dw))      # dw aliases the bucket slice: filled by flush_patch_weight_grads()
         else:
             patch_weight_grad(g, x, dw)
-        return None, dw, db, None, None
+        return None, dw, db, None, None, None
 
 
 def _colsum_two_stage(g: torch.Tensor, out: torch.Tensor, block: int = 256) -> torch.Tensor:
@@ -504,10 +515,21 @@ def fused_patch_coattn_supported(x, embed: int, n_q: int) -> bool:
     return x.dtype == torch.bfloat16 and x.shape[1] == 1024 and embed == 256 and n_q <= 8
 
 
-def patch_fc(x_bf16, weight, bias, drop_p: float, pre_gated_grad: bool = False):
-    h = PatchFcFn.apply(x_bf16, weight, bias, drop_p, pre_gated_grad)
+def patch_fc_kernel_supported(x, weight) -> bool:
+    """mpo_patch_fc_forward: a bf16 window through Linear(1024, 256)."""
+    return x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(weight.shape) == (256, 1024)
+
+
+def patch_fc(x_bf16, weight, bias, drop_p: float, pre_gated_grad: bool = False, batch: "BagBatch | None" = None):
+    """H_bag = dropout(relu(x W^T + b)), bf16.  batch (the window's row offsets / work plan): lets Linear(1024, 256) run as
+    one hand-written pass; the tensor then carries `_mpo_keep_scale` = 1 / (1 - realised dropout rate) for consumers that
+    apply the ReLU / dropout derivative themselves."""
+    h = PatchFcFn.apply(x_bf16, weight, bias, drop_p, pre_gated_grad, batch)
     if pre_gated_grad:
         h._mpo_bias_param = bias          # lets the consumer's backward write this layer's bias gradient in place
+    if drop_p > 0:
+        fused = batch is not None and patch_fc_kernel_supported(x_bf16, weight)
+        h._mpo_keep_scale = 1.0 / (1.0 - (_realised_drop(drop_p) if fused else drop_p))
     return h
 
 

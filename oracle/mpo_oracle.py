@@ -55,8 +55,8 @@ def patch_fc(wsi, p, prefix="H", keep=None, storage=None, round_gemm_out=True):
     """H_bag = Drop(ReLU(X W_H^T + b)); models/mcat/mcat.py:24-29,87.
     storage=torch.bfloat16 emulates the product's bf16 STORAGE points with fp32 arithmetic in between, so a bf16-stored
     run can be checked tightly: patch matrix, GEMM weight operand, H_bag -- and, with round_gemm_out, the GEMM output
-    before the bias (the library-GEMM path of NaCAGaT; MCAT's fused patch-layer kernel keeps the accumulator in fp32 up
-    to the one rounding of H_bag)."""
+    before the bias (the library-GEMM path of the small / big models; the hand-written patch-layer kernel of the medium
+    models keeps the accumulator in fp32 up to the one rounding of H_bag)."""
     x = wsi.squeeze(0) if wsi.dim() == 3 else wsi
     x = _store(x.float(), storage)
     h = x @ _store(p[prefix + ".0.weight"], storage).t()
@@ -250,9 +250,10 @@ def mcat_forward(p, wsi, omics, inference=False, bag_storage=None, fusion="conca
     return _tail(h_co, g_bag, a_co, p, fusion)
 
 
-def nacagat_forward(p, wsi, omics, bag_storage=None):
-    """NarrowContextualAttentionGateTransformer.forward, models/nacagat/nacagat.py:80-138 (eval mode)."""
-    h_bag = patch_fc(wsi, p, storage=bag_storage)
+def nacagat_forward(p, wsi, omics, bag_storage=None, round_gemm_out=False):
+    """NarrowContextualAttentionGateTransformer.forward, models/nacagat/nacagat.py:80-138 (eval mode).
+    bag_storage / round_gemm_out: see patch_fc (the 'medium' model's patch-layer kernel rounds H_bag once)."""
+    h_bag = patch_fc(wsi, p, storage=bag_storage, round_gemm_out=round_gemm_out)
     g_bag = omic_fc(omics, p)
     h_co, a_co = pregating_contextual_attention(g_bag, h_bag, p)
     return _tail(h_co, g_bag, a_co, p)

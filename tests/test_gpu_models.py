@@ -192,8 +192,8 @@ def test_small_model_size_matches_oracle(dev, kind, dtype):
     fwd = O.mcat_forward if kind == "mcat" else O.nacagat_forward
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     kw = dict(bag_storage=torch.bfloat16) if dtype == torch.bfloat16 else {}
-    if kw and kind == "mcat":
-        kw["round_gemm_out"] = True                       # (d = 128: the library-GEMM patch layer, not the fused kernel)
+    if kw:
+        kw["round_gemm_out"] = True                       # (d = 128: the library-GEMM patch layer, not the hand-written kernel)
     hz_o, sv_o, _, _ = fwd(p, wsi, omics, **kw)
     assert float((hz.cpu() - hz_o).abs().max()) < 2e-4
     O.ces_loss(hz_o, sv_o, label, censor).backward()

@@ -254,3 +254,34 @@ def test_token_pair_hands_both_token_sets_over_without_copies(dev):
     torch.testing.assert_close(gq1, gq0, rtol=1e-5, atol=1e-6)
     for k in g0:
         torch.testing.assert_close(g1[k], g0[k], rtol=1e-5, atol=1e-6)
+
+
+def test_patch_layer_alone_is_the_fused_kernel_without_its_co_attention(dev):
+    """mpo_patch_fc_forward (the fused kernel with its co-attention slices off): H_bag must be bit for bit what the fused
+    forward writes -- eval and, with the same Philox stream, training mode -- on a ragged window with partial blocks; the
+    autograd wrapper (ops.patch_fc with a batch) must give the patch layer's gradients."""
+    lengths = [1, 127, 129, 700, 2049]
+    p = _params(41)
+    bags, query = _inputs(lengths, 42)
+    batch = BagBatch.from_list([b.to(dev).to(torch.bfloat16) for b in bags])
+    w, bias = p["H.0.weight"].to(dev).requires_grad_(True), p["H.0.bias"].to(dev).requires_grad_(True)
+    for drop_p in (0.0, 0.25):
+        ops._rng_calls = 500
+        _, _, h_fused, _ = ops.patch_coattn_mcat(batch.data, batch, w, bias, drop_p, query.to(dev),
+                                                 p["co_attention.in_proj_weight"].to(dev), p["co_attention.in_proj_bias"].to(dev),
+                                                 p["co_attention.out_proj.weight"].to(dev), p["co_attention.out_proj.bias"].to(dev), False)
+        ops._rng_calls = 500
+        h = ops.patch_fc(batch.data, w, bias, drop_p, batch=batch)
+        assert torch.equal(h, h_fused)
+        if drop_p > 0:
+            assert abs(h._mpo_keep_scale - 1.0 / 0.75) < 1e-12
+    # eval-mode values against the oracle on the same stored operands, gradients against autograd on those
+    x = batch.data.float()
+    wr, br = p["H.0.weight"].to(dev).bfloat16().float().requires_grad_(True), p["H.0.bias"].to(dev).clone().requires_grad_(True)
+    ref = torch.relu(x @ wr.t() + br)
+    h = ops.patch_fc(batch.data, w, bias, 0.0, batch=batch)
+    assert relmax(h.float(), ref.detach()) < 2.0 ** -7
+    probe = torch.randn_like(ref) * 0.01
+    gw, gb = torch.autograd.grad((h.float() * probe).sum(), [w, bias])
+    (ref * probe.bfloat16().float()).sum().backward()
+    assert relmax(gw, wr.grad) < 5e-3 and relmax(gb, br.grad) < 5e-3
