@@ -7,7 +7,8 @@
 // this mix of matrix and memory work the chip clocks down (GRBM cycles / time: 2.4 GHz streaming only, 2.05 GHz MFMA
 // only, 1.3-1.6 GHz both), so fewer cycles bought less time than they should (NOTES.md r02-dW_H).
 //
-// One workgroup per CU, 256 of them = 64 row ranges x 4 column blocks of X; a workgroup accumulates the 256 x 256 block
+// One workgroup per CU, 256 of them = 64 row ranges x 4 column blocks of X (256 x 1 for a 256-wide X: the key-projection
+// weight gradient of NaCAGaT, d_k^T H_bag); a workgroup accumulates the 256 x 256 block
 //   dW[:, 256 cb ..] += g[rows]^T X[rows, 256 cb ..]
 // of its row range in registers (8 waves x 32 accumulator tiles) and writes one fp32 partial; a second launch sums the 64
 // partials.  The four column blocks of a row range read the same g rows: they sit on the SAME XCD (blockIdx -> XCD is
@@ -31,7 +32,7 @@ constexpr int WG_TILE = WG_BK * 512;         // 16 KiB image
 constexpr int WG_STAGE = 2 * WG_TILE;        // g image | x image
 constexpr int WG_LDS = WG_STAGES * WG_STAGE; // 128 KiB
 constexpr int WG_WAVES = 8;
-constexpr int WG_RANGES = 64;
+constexpr int WG_WGS = 256;                  // workgroups per launch: row ranges x column blocks, one per CU
 
 __device__ __forceinline__ void wait_vm(int n) {
     // n = wave-instructions that may stay outstanding; 4 per chunk and wave
@@ -187,7 +188,10 @@ void patch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict
 
 }  // namespace
 
-size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim) { return (size_t)WG_RANGES * embed * patch_dim; }
+size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim) {
+    const int n_cb = patch_dim / WG_CB > 0 ? patch_dim / WG_CB : 1;
+    return (size_t)(WG_WGS / n_cb) * embed * patch_dim;
+}
 
 int mpo_launch_patch_wgrad(const void* g, const void* x, int total_rows, int embed, int patch_dim, float* part, float* d_weight,
                            hipStream_t stream) {
@@ -197,7 +201,7 @@ int mpo_launch_patch_wgrad(const void* g, const void* x, int total_rows, int emb
     MPO_CHECK((uint64_t)total_rows * (uint64_t)patch_dim * 2 < ((uint64_t)1 << 32), "patch weight gradient: patch matrix of 4 GiB or more");
     MPO_CHECK(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x)) & 15) == 0, "patch weight gradient: operands must be 16-byte aligned");
     const int n_cb = patch_dim / WG_CB;
-    const int ranges = WG_RANGES;                                   // ranges * n_cb workgroups; 256 at patch_dim 1024
+    const int ranges = WG_WGS / n_cb;                               // 64 row ranges at patch_dim 1024, 256 at 256
     const int rpr = ((total_rows + ranges - 1) / ranges + WG_BK - 1) / WG_BK * WG_BK;
     patch_wgrad_kernel<<<ranges * n_cb, WG_WAVES * 64, 0, stream>>>(static_cast<const __bf16*>(g), static_cast<const __bf16*>(x),
                                                                   total_rows, patch_dim, rpr, part);

@@ -1121,7 +1121,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
                                                L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_nacagat_patch_grad")
             if colsum is not None:
                 d_h._mpo_colsum = colsum          # the producing layer's bias gradient (PatchFcFn.backward picks it up)
-            _splitk_tn(d_k, bag_data, d_in_w[E:2 * E])
+            patch_weight_grad(d_k, bag_data, d_in_w[E:2 * E])     # dW_k = d_k^T H_bag (hand-written for 256 x 256, bf16)
         else:
             d_h.addmm_(d_k, w_k)
             torch.mm(d_k.t(), bag_data, out=d_in_w[E:2 * E])
