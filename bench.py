@@ -110,18 +110,27 @@ def make_windows(n_windows, window, patches, dev, bag_dtype, seed, ragged=False,
     return out
 
 
-def _time_launches(dev, launch, reps, burst=4):
-    """HIP-event timing on the launching stream.  One event pair brackets a burst of back-to-back launches (alternating
-    resident inputs): a pair around a single launch also times that launch's dispatch latency (~3 us, which rocprofv3's
-    kernel duration does not contain); inside a burst the next dispatch overlaps the running kernel, as it does in the
-    captured window step.  Returns sorted per-launch microseconds."""
+def _time_launches(dev, launch, reps, burst=4, between=None):
+    """HIP-event timing on the launching stream.
+    between is None: one event pair brackets a burst of back-to-back launches (alternating resident inputs): a pair around
+      a single launch also times that launch's dispatch latency (~3 us, which rocprofv3's kernel duration does not
+      contain); inside a burst the next dispatch overlaps the running kernel.
+    between given: every timed launch is preceded by between(i) -- one replay of the captured window step -- so the kernel
+      is timed in the state the chip has when it runs inside the workload.  Back-to-back launches of a kernel that mixes
+      250 GF of MFMA work with a 1.2 GB stream hold the chip in a lower clock state than the step does (DESIGN.md section 3,
+      dW_H): the burst figure of such a kernel is ~15 % worse than what the same kernel takes inside the step.
+    Returns (sorted per-launch microseconds, launches per event pair)."""
     import torch
     stream = torch.cuda.current_stream(dev)
     for i in range(3):
         launch(i)
     torch.cuda.synchronize(dev)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    if between is not None:
+        burst = 1
     for i, (s, e) in enumerate(evs):
+        if between is not None:
+            between(i)
         s.record(stream)
         for j in range(burst):
             launch(i * burst + j)
@@ -144,7 +153,7 @@ def _stored_profile(name, avg_us, applies):
     return prof.get("hbm_bytes_per_launch"), util, "profiles/" + name
 
 
-def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
+def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=None):
     """Time the model's long-bag cross-attention forward kernel alone over a window of bags against its ALGORITHMIC bytes
     (DESIGN.md section 3):
       MCAT, bf16 window (the headline): the fused patch-layer + co-attention pass (row f1): reads the raw patch matrix
@@ -204,11 +213,12 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20):
         name = "bag_rowdot_gated_exact_kernel<256> (f32 key bag)" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
         tname = "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json"
         applies = window == 32 and patches == 15000 and (k2 or esz == 2)
-    us, burst = _time_launches(dev, launch, reps)
+    extra = {"timing": "each launch preceded by one replay of the window step"} if between is not None else {}
+    us, burst = _time_launches(dev, launch, reps, between=between)
     avg_us = sum(us) / len(us)
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
     traffic, mfma_util, source = _stored_profile(tname, avg_us, applies)
-    return {"bound": "hbm", "kernel": name,
+    return {**extra, "bound": "hbm", "kernel": name,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_util": mfma_util,
             "traffic_source": source,
@@ -337,13 +347,15 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
                        "patches_per_slide": "uniform[2000,30000] (fixed multiset)" if a.ragged else a.patches,
                        "parallelism": f"dp{world}", "resident_windows": a.n_windows, "launch": graph_note},
         }
+    if rank == 0 and with_roofline:
+        # the roofline kernel is timed inside the workload it belongs to: a replay of the captured step before every
+        # timed launch (single process; with several ranks the step contains collectives: back-to-back launches there)
+        between = (lambda i: step(i)) if (world == 1 and graphed is not None) else None
+        out["roofline"] = roofline_leg(dev, a.window, a.patches if not a.ragged else 16000, bag_dtype, a.model, between=between)
     # release this configuration's graphs and windows before the next one is built
     del graphed, windows, opt, bucket, model
     gc.collect()
     torch.cuda.empty_cache()
-    if rank == 0 and with_roofline:
-        out["roofline"] = roofline_leg(dev, a.window, a.patches if not a.ragged else 16000, bag_dtype, a.model)
-        torch.cuda.empty_cache()
     return out
 
 
