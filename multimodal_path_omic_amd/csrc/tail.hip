@@ -103,143 +103,162 @@ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, co
 // qkv [B*T][3d] (q | k | v), H heads of hd = d / H.  One workgroup per slide, everything through LDS.
 constexpr int kMaxT = 16;
 
-// global -> LDS copy of n floats by the 256 threads of a workgroup: up to eight independent 16-byte loads per thread in
-// flight (a plain `for (i = tid; i < n; i += 256) dst[i] = src[i]` becomes load, wait, store, 18 times over: the 11 us of
-// the forward kernel and 14 us of the backward were mostly that chain)
-__device__ __forceinline__ void stage_to_lds(float* dst, const float* __restrict__ src, int n, int tid) {
-    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
-        const int n4 = n >> 2;
-        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-        f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-        for (int base = 0; base < n4; base += 8 * 256) {
-            f32x4 v[8];
+// One WAVE per (slide, head): the four waves of a workgroup take four consecutive (slide, head) pairs and never wait for
+// each other beyond the workgroup barriers between phases.  (First version: one workgroup per slide, everything for its 8
+// heads through LDS in five phases, the softmax + dropout phase on 48 threads with six Philox draws each: 11 us forward,
+// 14 us backward for 64 slides -- the latency of the phases, not the work.)
+// LDS of a wave: q | k | v rows of its head [3][T][hd], then scratch.
+__device__ __forceinline__ void mha_load_head(float* sq, const float* __restrict__ qkv, int b, int h, int T, int d, int hd, int lane) {
+    // row (part, i) of the head: hd contiguous floats at qkv[(b T + i) 3d + part d + h hd]
+    const int n = 3 * T * hd;
+    for (int base = 0; base < n; base += 4 * 64) {
+        float v[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = base + k * 256 + tid;
-                v[k] = s4[i < n4 ? i : 0];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = base + k * 256 + tid;
-                if (i < n4) d4[i] = v[k];
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int idx = base + k * 64 + lane;
+            const int ii = idx < n ? idx : 0;
+            const int part = ii / (T * hd), i = (ii / hd) % T, c = ii % hd;
+            v[k] = qkv[((size_t)b * T + i) * 3 * d + part * d + h * hd + c];
         }
-        for (int i = (n4 << 2) + tid; i < n; i += 256) dst[i] = src[i];
-    } else {
-        for (int i = tid; i < n; i += 256) dst[i] = src[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = base + k * 64 + lane;
+            if (idx < n) sq[idx] = v[k];
+        }
     }
 }
 
 __global__ __launch_bounds__(256)
 void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ p_save /* [B][H][T][T] x2: p, p_post */,
-                          int T, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset_,
+                          int B, int T, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset_,
                           const unsigned long long* epoch) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const unsigned long long offset = epoch_offset(offset_, epoch);
-    float* sq = sm;                       // [T][3d]
-    float* sp = sm + T * 3 * d;           // [H][T][T]
-    const int b = blockIdx.x, hd = d / H, tid = threadIdx.x;
+    const int hd = d / H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_wave = 3 * T * hd + 2 * T * T + 2 * T;
+    float* sq = sm + wave * per_wave;     // [3][T][hd]
+    float* sp = sq + 3 * T * hd;          // [T][T] scores, then p_post
+    float* sst = sp + 2 * T * T;          // [T] row max, [T] 1 / row sum
+    const int gid = blockIdx.x * 4 + wave;
+    const bool live = gid < B * H;
+    const int b = live ? gid / H : 0, h = live ? gid % H : 0;
     const float scale = rsqrtf((float)hd);
-    stage_to_lds(sq, qkv + (size_t)b * T * 3 * d, T * 3 * d, tid);
+    if (live) mha_load_head(sq, qkv, b, h, T, d, hd, lane);
     __syncthreads();
-    for (int it = tid; it < H * T * T; it += 256) {
-        const int h = it / (T * T), i = (it / T) % T, j = it % T;
-        const float* qi = sq + i * 3 * d + h * hd;
-        const float* kj = sq + j * 3 * d + d + h * hd;
-        // every (h, i, j) row starts on the same LDS bank (offsets are multiples of hd = 32 floats): walk the head
-        // dimension from a per-thread rotation so that the lanes of a wave hit different banks
-        const int rot = tid % hd;
-        float s = 0.f;
-        for (int c = 0; c < hd; ++c) {
-            const int cc = c + rot < hd ? c + rot : c + rot - hd;
-            s += qi[cc] * kj[cc];
+    if (live) {
+        for (int it = lane; it < T * T; it += 64) {
+            const int i = it / T, j = it % T;
+            const float* qi = sq + i * hd;
+            const float* kj = sq + (T + j) * hd;
+            // the rows of all (i, j) start on the same LDS banks: walk the head dimension from a per-lane rotation
+            const int rot = lane % hd;
+            float s = 0.f;
+            for (int c = 0; c < hd; ++c) {
+                const int cc = c + rot < hd ? c + rot : c + rot - hd;
+                s += qi[cc] * kj[cc];
+            }
+            sp[it] = s * scale;
         }
-        sp[it] = s * scale;
     }
     __syncthreads();
-    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    float* pb = p_save + (size_t)b * 2 * H * T * T;
-    for (int it = tid; it < H * T; it += 256) {
-        float* row = sp + it * T;
+    if (live && lane < T) {
+        const float* row = sp + lane * T;
         float mx = row[0];
         for (int j = 1; j < T; ++j) mx = fmaxf(mx, row[j]);
         float l = 0.f;
-        for (int j = 0; j < T; ++j) { row[j] = __expf(row[j] - mx); l += row[j]; }
-        const float inv = 1.0f / l;
-        for (int j = 0; j < T; ++j) {
-            const float p = row[j] * inv;
+        for (int j = 0; j < T; ++j) l += __expf(row[j] - mx);
+        sst[lane] = mx;
+        sst[T + lane] = 1.0f / l;
+    }
+    __syncthreads();
+    if (live) {
+        const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+        float* pb = p_save + (size_t)b * 2 * H * T * T;
+        for (int it = lane; it < T * T; it += 64) {
+            const int i = it / T;
+            const int row_g = h * T + i;                                         // row index of the [H T][T] layout
+            const float p = __expf(sp[it] - sst[i]) * sst[T + i];
             float pp = p;
-            if (drop_p > 0.f) pp *= dropout_keep(seed, offset, ((size_t)b * H * T + it) * T + j, drop_p, inv_keep);
-            pb[it * T + j] = p;
-            pb[H * T * T + it * T + j] = pp;
-            row[j] = pp;
+            if (drop_p > 0.f) pp *= dropout_keep(seed, offset, ((size_t)b * H * T + row_g) * T + (it % T), drop_p, inv_keep);
+            pb[row_g * T + (it % T)] = p;
+            pb[H * T * T + row_g * T + (it % T)] = pp;
+            sp[T * T + it] = pp;
         }
     }
     __syncthreads();
-    for (int it = tid; it < T * d; it += 256) {
-        const int i = it / d, c = it % d, h = c / hd;
-        const float* pr = sp + (h * T + i) * T;
-        float a = 0.f;
-        for (int j = 0; j < T; ++j) a += pr[j] * sq[j * 3 * d + 2 * d + c];
-        o[((size_t)b * T + i) * d + c] = a;
+    if (live) {
+        for (int idx = lane; idx < T * hd; idx += 64) {
+            const int i = idx / hd, c = idx % hd;
+            const float* pr = sp + T * T + i * T;
+            float a = 0.f;
+            for (int j = 0; j < T; ++j) a += pr[j] * sq[(2 * T + j) * hd + c];
+            o[((size_t)b * T + i) * d + h * hd + c] = a;
+        }
     }
 }
 
 __global__ __launch_bounds__(256)
 void mha_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ p_save, const float* __restrict__ d_o,
-                          float* __restrict__ dqkv, int T, int d, int H) {
+                          float* __restrict__ dqkv, int B, int T, int d, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sq = sm;                       // [T][3d]
-    float* sdo = sq + T * 3 * d;          // [T][d]
-    float* sds = sdo + T * d;             // [H][T][T]  dS
-    float* sdp = sds + H * T * T;         // [H][T][T]  dP
-    float* spp = sdp + H * T * T;         // [2][H][T][T]  P, P after dropout (saved by the forward)
-    const int b = blockIdx.x, hd = d / H, tid = threadIdx.x;
+    const int hd = d / H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_wave = 4 * T * hd + 4 * T * T;
+    float* sq = sm + wave * per_wave;     // [3][T][hd]
+    float* sdo = sq + 3 * T * hd;         // [T][hd]
+    float* spp = sdo + T * hd;            // [2][T][T]  P, P after dropout
+    float* sdp = spp + 2 * T * T;         // [T][T]  dP * keep-scale
+    float* sds = sdp + T * T;             // [T][T]  dS
+    const int gid = blockIdx.x * 4 + wave;
+    const bool live = gid < B * H;
+    const int b = live ? gid / H : 0, h = live ? gid % H : 0;
     const float scale = rsqrtf((float)hd);
-    stage_to_lds(sq, qkv + (size_t)b * T * 3 * d, T * 3 * d, tid);
-    stage_to_lds(sdo, d_o + (size_t)b * T * d, T * d, tid);
-    stage_to_lds(spp, p_save + (size_t)b * 2 * H * T * T, 2 * H * T * T, tid);
-    __syncthreads();
-    const float* pb = spp;
-    const float* ppb = pb + H * T * T;
-    // dP[h][i][j] = do[i] . v[j] over the head's columns: one thread per (h, i, j), bank-rotated as in the forward
-    for (int it = tid; it < H * T * T; it += 256) {
-        const int h = it / (T * T), i = (it / T) % T, j = it % T;
-        const float* vj = sq + j * 3 * d + 2 * d + h * hd;
-        const float* doi = sdo + i * d + h * hd;
-        const int rot = tid % hd;
-        float a = 0.f;
-        for (int c = 0; c < hd; ++c) {
-            const int cc = c + rot < hd ? c + rot : c + rot - hd;
-            a += doi[cc] * vj[cc];
+    if (live) {
+        mha_load_head(sq, qkv, b, h, T, d, hd, lane);
+        for (int idx = lane; idx < T * hd; idx += 64) sdo[idx] = d_o[((size_t)b * T + idx / hd) * d + h * hd + idx % hd];
+        const float* pb = p_save + (size_t)b * 2 * H * T * T;
+        for (int it = lane; it < T * T; it += 64) {
+            spp[it] = pb[(h * T) * T + it];
+            spp[T * T + it] = pb[H * T * T + (h * T) * T + it];
         }
-        sdp[it] = a;
     }
     __syncthreads();
-    for (int it = tid; it < H * T; it += 256) {
-        float dp[kMaxT];
+    if (live) {
+        // dP[i][j] = do[i] . v[j], times the dropout keep-scale of (i, j)
+        for (int it = lane; it < T * T; it += 64) {
+            const int i = it / T, j = it % T;
+            const float* vj = sq + (2 * T + j) * hd;
+            const float* doi = sdo + i * hd;
+            const int rot = lane % hd;
+            float a = 0.f;
+            for (int c = 0; c < hd; ++c) {
+                const int cc = c + rot < hd ? c + rot : c + rot - hd;
+                a += doi[cc] * vj[cc];
+            }
+            const float p = spp[it];
+            sdp[it] = a * (p > 0.f ? spp[T * T + it] / p : 0.f);
+        }
+    }
+    __syncthreads();
+    if (live && lane < T) {
         float delta = 0.f;
-        for (int j = 0; j < T; ++j) {
-            const float p = pb[it * T + j];
-            const float ks = p > 0.f ? ppb[it * T + j] / p : 0.f;
-            dp[j] = sdp[it * T + j] * ks;
-            delta += p * dp[j];
-        }
-        for (int j = 0; j < T; ++j) sds[it * T + j] = pb[it * T + j] * (dp[j] - delta) * scale;
+        for (int j = 0; j < T; ++j) delta += spp[lane * T + j] * sdp[lane * T + j];
+        for (int j = 0; j < T; ++j) sds[lane * T + j] = spp[lane * T + j] * (sdp[lane * T + j] - delta) * scale;
     }
     __syncthreads();
-    float* out = dqkv + (size_t)b * T * 3 * d;
-    for (int it = tid; it < T * d; it += 256) {
-        const int t = it / d, c = it % d, h = c / hd;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
-        for (int u = 0; u < T; ++u) {
-            dq += sds[(h * T + t) * T + u] * sq[u * 3 * d + d + c];          // dS[t][u] k[u]
-            dk += sds[(h * T + u) * T + t] * sq[u * 3 * d + c];              // dS[u][t] q[u]
-            dv += ppb[(h * T + u) * T + t] * sdo[u * d + c];                 // Ppost[u][t] do[u]
+    if (live) {
+        for (int idx = lane; idx < T * hd; idx += 64) {
+            const int t = idx / hd, c = idx % hd;
+            float dq = 0.f, dk = 0.f, dv = 0.f;
+            for (int u = 0; u < T; ++u) {
+                dq += sds[t * T + u] * sq[(T + u) * hd + c];                   // dS[t][u] k[u]
+                dk += sds[u * T + t] * sq[u * hd + c];                         // dS[u][t] q[u]
+                dv += spp[T * T + u * T + t] * sdo[u * hd + c];                // Ppost[u][t] do[u]
+            }
+            float* out = dqkv + ((size_t)b * T + t) * 3 * d + h * hd + c;
+            out[0] = dq;
+            out[d] = dk;
+            out[2 * d] = dv;
         }
-        out[t * 3 * d + c] = dq;
-        out[t * 3 * d + d + c] = dk;
-        out[t * 3 * d + 2 * d + c] = dv;
     }
 }
 
@@ -575,17 +594,20 @@ int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, i
                              unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
                              hipStream_t s) {
     MPO_CHECK(T >= 1 && T <= kMaxT && d % H == 0, "set-transformer attention: T=%d (max %d), d=%d, heads=%d", T, kMaxT, d, H);
-    const size_t lds = ((size_t)T * 3 * d + (size_t)H * T * T) * sizeof(float);
-    mha_small_fwd_kernel<<<B, 256, lds, s>>>(qkv, o, p_save, T, d, H, drop_p, seed, offset, epoch);
+    const int hd = d / H;
+    const size_t lds = 4 * ((size_t)3 * T * hd + 2 * T * T + 2 * T) * sizeof(float);
+    MPO_CHECK(lds <= 160 * 1024, "set-transformer attention: T=%d, head dim %d needs %zu bytes of LDS", T, hd, lds);
+    mha_small_fwd_kernel<<<(B * H + 3) / 4, 256, lds, s>>>(qkv, o, p_save, B, T, d, H, drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }
 int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float* d_o, float* dqkv, int B, int T, int d, int H,
                              hipStream_t s) {
     MPO_CHECK(T >= 1 && T <= kMaxT && d % H == 0, "set-transformer attention: T=%d (max %d), d=%d, heads=%d", T, kMaxT, d, H);
-    const size_t lds = ((size_t)T * 4 * d + (size_t)4 * H * T * T) * sizeof(float);
-    MPO_CHECK(lds <= 160 * 1024, "set-transformer attention backward: T=%d, d=%d needs %zu bytes of LDS", T, d, lds);
-    mha_small_bwd_kernel<<<B, 256, lds, s>>>(qkv, p_save, d_o, dqkv, T, d, H);
+    const int hd = d / H;
+    const size_t lds = 4 * ((size_t)4 * T * hd + 4 * T * T) * sizeof(float);
+    MPO_CHECK(lds <= 160 * 1024, "set-transformer attention backward: T=%d, head dim %d needs %zu bytes of LDS", T, hd, lds);
+    mha_small_bwd_kernel<<<(B * H + 3) / 4, 256, lds, s>>>(qkv, p_save, d_o, dqkv, B, T, d, H);
     MPO_LAUNCH_CHECK();
     return 0;
 }
