@@ -173,6 +173,36 @@ def test_window_equals_per_slide(dev, kind, lengths):
 
 
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])
+def test_full_size_bf16_training_window_equals_per_slide(dev, kind):
+    """BASELINE's bag length (15 000 patches, bf16 storage) through the TRAINING-step path of the harness -- the fused
+    patch layer + co-attention (MCAT) / patch-layer kernel + K2 (NaCAGaT), token pair, interleaved pooling, head + loss in
+    one launch, hand-written dW_H -- against the same slides one at a time through the module's forward() and the separate
+    loss launches.  Size-independent property: a window is the sum of its slides (losses equal, gradients add up)."""
+    from multimodal_path_omic_amd import harness
+    omic_sizes, seed, n, m = [256] * 6, 991, 6, 15000
+    model, _ = build(kind, omic_sizes, seed, dev, bag_dtype=torch.bfloat16)
+    g = syn.rng(seed)
+    wsis = [syn.normal(g, (m, 1024)).to(dev).to(torch.bfloat16) for _ in range(n)]
+    omics = [[syn.normal(g, (s,)).to(dev) for s in omic_sizes] for _ in range(n)]
+    labels = (torch.arange(n) % 4).to(dev)
+    cens = (torch.arange(n) % 2).float().to(dev)
+    bags = BagBatch.from_list(wsis)
+    om_w = [torch.stack([omics[b][i] for b in range(n)]) for i in range(len(omic_sizes))]
+    per_slide, risk = harness.train_window(model, bags, om_w, labels, cens, grad_acc_step=n)
+    grads_w = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    for b in range(n):
+        hz, sv, y, att = model(wsi=wsis[b], omics=omics[b])
+        loss = ces_loss(hz, sv, labels[b:b + 1], cens[b:b + 1])
+        assert abs(float(loss) - float(per_slide[b])) < 2e-5 * max(1.0, abs(float(loss))), (b, float(loss), float(per_slide[b]))
+        assert abs(float(-sv.sum()) - float(risk[b])) < 1e-5
+        (loss / n).backward()
+    for k, p in model.named_parameters():
+        scale = max(float(p.grad.abs().max()), 1e-3)
+        assert float((grads_w[k] - p.grad).abs().max()) / scale < 5e-4, k
+
+
+@pytest.mark.parametrize("kind", ["mcat", "nacagat"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_small_model_size_matches_oracle(dev, kind, dtype):
     """model_size='small' (d = 128, models/mcat/mcat.py:16-17): the E = 128 instantiations of every bag kernel, forward
