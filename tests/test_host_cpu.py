@@ -108,3 +108,32 @@ def test_unbuilt_model_size_is_refused_at_construction():
         NarrowContextualAttentionGateTransformer(omic_sizes=[8] * 6, model_size="big")
     MultimodalCoAttentionTransformer(omic_sizes=[8] * 6, model_size="big")          # MCAT 'big' is built
     NarrowContextualAttentionGateTransformer(omic_sizes=[8] * 6, model_size="small")
+
+
+def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` outside a torchrun environment: N rank processes through torch.distributed.run on
+    127.0.0.1, this process neither touches the GPU nor is replaced (the box refuses an exec from a process that did)."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class _Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return _Done()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert bench.self_launch(bench.parse(argv), argv) == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
