@@ -27,6 +27,14 @@ class BagBatch:
     lengths: List[int]
     _plan: object = None
 
+    def __post_init__(self):
+        # an empty bag has no softmax (the reference's nn.MultiheadAttention returns NaN for it): refuse it here, before a
+        # workgroup-less slide reaches the kernels
+        if len(self.lengths) == 0 or any(int(m) <= 0 for m in self.lengths):
+            raise ValueError(f"every slide of a window needs at least one patch row (lengths {list(self.lengths)[:8]}...)")
+        if int(self.data.shape[0]) != sum(int(m) for m in self.lengths):
+            raise ValueError(f"{int(self.data.shape[0])} rows for lengths summing to {sum(self.lengths)}")
+
     def plan(self):
         """Work plan of the bag passes (mpo_bag_plan): rows per workgroup uniform over the whole window, so every
         slide gets row ranges in proportion to its length.  Built once per window (one small H2D copy), kept alive

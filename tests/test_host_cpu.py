@@ -137,3 +137,13 @@ def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_empty_slides_are_refused():
+    import torch
+    from multimodal_path_omic_amd.ops import BagBatch
+    x = torch.zeros(5, 8)
+    with pytest.raises(ValueError, match="at least one patch"):
+        BagBatch.from_lengths(x, [5, 0])
+    with pytest.raises(ValueError):
+        BagBatch.from_lengths(x, [3, 3])
