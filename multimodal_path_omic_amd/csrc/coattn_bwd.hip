@@ -418,7 +418,7 @@ void coattn_bwd_kernel(const void* __restrict__ bag_, const int* __restrict__ cu
     }
 }
 
-// The small work that follows a split-M bag pass, in ONE launch (each used to be its own 4.7 us graph node):
+// The small work that follows a split-M bag pass, in ONE launch (each used to be its own dependent launch):
 //   rows y < n_slides * n_red : out_k[b][i] = sum_s part_k[s][i] over slide b's workgroups (64 float4 columns per
 //                               workgroup, the 4 waves split the partials);
 //   the extra row y == n_slides * n_red : column sums over ALL partials (colsum[c] = sum_s part_cs[s][c], the bias

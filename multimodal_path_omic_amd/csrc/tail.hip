@@ -414,7 +414,7 @@ __global__ void ces_loss_bwd_kernel(const float* __restrict__ hazards, const flo
 
 // Training step: survival head, 'ces' loss and BOTH their backward passes for a slide, one thread, one launch: the
 // loss's upstream gradient w[b] is known before the forward in a training step (1 / grad_acc_step per slide), and four
-// dependent 4.7 us graph nodes (head, loss, d loss, d head) are one.  Same arithmetic as the four kernels above.
+// dependent launches (head, loss, d loss, d head) are one.  Same arithmetic as the four kernels above.
 __global__ void head_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
                                  const float* __restrict__ cens, const float* __restrict__ w,
                                  float* __restrict__ hazards, float* __restrict__ survs, float* __restrict__ y,
