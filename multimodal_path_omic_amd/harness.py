@@ -116,7 +116,7 @@ class GraphedWindowStep:
     """
 
     def __init__(self, model, bucket, window, grad_acc_step: int, opt=None, warmup: int = 2, pool=None,
-                 split_patch_grad: bool = False):
+                 split_patch_grad: bool = False, prime: bool = True):
         """split_patch_grad (data-parallel steps, opt=None): the patch layer's weight gradient -- a 0.3 ms GEMM nobody
         downstream waits for -- is captured into a SECOND graph, `replay_tail()`.  The caller replays the main graph,
         starts the all-reduce of every other gradient (bucket.all_reduce_mean_async(lo=head)), replays the tail while
@@ -156,6 +156,20 @@ class GraphedWindowStep:
             self.tail_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.tail_graph, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 ops.flush_patch_weight_grads()
+        # The FIRST replay of a captured graph pays for its upload (2-4 ms against a 1.2 ms step, measured): pay it here,
+        # with the state it touches put back, so that a caller's first step is a step like any other.
+        if prime:
+            grads = bucket.flat.clone()
+            for _ in range(2):
+                self.graph.replay()
+                if self.tail_graph is not None:
+                    self.tail_graph.replay()
+            if keep is not None:
+                for t, k in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.t_dev), keep):
+                    t.copy_(k)
+            self.epoch.copy_(keep_epoch)
+            bucket.flat.copy_(grads)
+            torch.cuda.current_stream(dev).synchronize()
 
     def _body(self, flush: bool = True):
         from . import ops
