@@ -111,30 +111,35 @@ constexpr int kMaxT = 16;
 __device__ __forceinline__ void mha_load_head(float* sq, const float* __restrict__ qkv, int b, int h, int T, int d, int hd, int lane) {
     // row (part, i) of the head: hd contiguous floats at qkv[(b T + i) 3d + part d + h hd]
     const int n = 3 * T * hd;
-    for (int base = 0; base < n; base += 4 * 64) {
-        float v[4];
+    for (int base = 0; base < n; base += 12 * 64) {         // (576 values at T = 6, hd = 32: one round of nine loads)
+        float v[12];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 12; ++k) {
             const int idx = base + k * 64 + lane;
             const int ii = idx < n ? idx : 0;
             const int part = ii / (T * hd), i = (ii / hd) % T, c = ii % hd;
             v[k] = qkv[((size_t)b * T + i) * 3 * d + part * d + h * hd + c];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 12; ++k) {
             const int idx = base + k * 64 + lane;
             if (idx < n) sq[idx] = v[k];
         }
     }
 }
 
+// TC / HDC: compile-time T and head dimension (0: run-time values).  With run-time loop bounds every LDS read of the dot
+// and context loops is waited for before the next is issued; the model's shape (T = 6 tokens, head dimension 32) gets
+// fully unrolled loops.
+template <int TC, int HDC>
 __global__ __launch_bounds__(256)
 void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ p_save /* [B][H][T][T] x2: p, p_post */,
-                          int B, int T, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset_,
+                          int B, int T_, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset_,
                           const unsigned long long* epoch) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const unsigned long long offset = epoch_offset(offset_, epoch);
-    const int hd = d / H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = TC ? TC : T_;
+    const int hd = HDC ? HDC : d / H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_wave = 3 * T * hd + 2 * T * T + 2 * T;
     float* sq = sm + wave * per_wave;     // [3][T][hd]
     float* sp = sq + 3 * T * hd;          // [T][T] scores, then p_post
@@ -153,6 +158,7 @@ void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, 
             // the rows of all (i, j) start on the same LDS banks: walk the head dimension from a per-lane rotation
             const int rot = lane % hd;
             float s = 0.f;
+#pragma unroll
             for (int c = 0; c < hd; ++c) {
                 const int cc = c + rot < hd ? c + rot : c + rot - hd;
                 s += qi[cc] * kj[cc];
@@ -191,17 +197,20 @@ void mha_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, 
             const int i = idx / hd, c = idx % hd;
             const float* pr = sp + T * T + i * T;
             float a = 0.f;
+#pragma unroll
             for (int j = 0; j < T; ++j) a += pr[j] * sq[(2 * T + j) * hd + c];
             o[((size_t)b * T + i) * d + h * hd + c] = a;
         }
     }
 }
 
+template <int TC, int HDC>
 __global__ __launch_bounds__(256)
 void mha_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ p_save, const float* __restrict__ d_o,
-                          float* __restrict__ dqkv, int B, int T, int d, int H) {
+                          float* __restrict__ dqkv, int B, int T_, int d, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hd = d / H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = TC ? TC : T_;
+    const int hd = HDC ? HDC : d / H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_wave = 4 * T * hd + 4 * T * T;
     float* sq = sm + wave * per_wave;     // [3][T][hd]
     float* sdo = sq + 3 * T * hd;         // [T][hd]
@@ -230,6 +239,7 @@ void mha_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict
             const float* doi = sdo + i * hd;
             const int rot = lane % hd;
             float a = 0.f;
+#pragma unroll
             for (int c = 0; c < hd; ++c) {
                 const int cc = c + rot < hd ? c + rot : c + rot - hd;
                 a += doi[cc] * vj[cc];
@@ -249,6 +259,7 @@ void mha_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict
         for (int idx = lane; idx < T * hd; idx += 64) {
             const int t = idx / hd, c = idx % hd;
             float dq = 0.f, dk = 0.f, dv = 0.f;
+#pragma unroll
             for (int u = 0; u < T; ++u) {
                 dq += sds[t * T + u] * sq[(T + u) * hd + c];                   // dS[t][u] k[u]
                 dk += sds[u * T + t] * sq[u * hd + c];                         // dS[u][t] q[u]
@@ -597,7 +608,8 @@ int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, i
     const int hd = d / H;
     const size_t lds = 4 * ((size_t)3 * T * hd + 2 * T * T + 2 * T) * sizeof(float);
     MPO_CHECK(lds <= 160 * 1024, "set-transformer attention: T=%d, head dim %d needs %zu bytes of LDS", T, hd, lds);
-    mha_small_fwd_kernel<<<(B * H + 3) / 4, 256, lds, s>>>(qkv, o, p_save, B, T, d, H, drop_p, seed, offset, epoch);
+    if (T == 6 && hd == 32) mha_small_fwd_kernel<6, 32><<<(B * H + 3) / 4, 256, lds, s>>>(qkv, o, p_save, B, T, d, H, drop_p, seed, offset, epoch);
+    else mha_small_fwd_kernel<0, 0><<<(B * H + 3) / 4, 256, lds, s>>>(qkv, o, p_save, B, T, d, H, drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }
@@ -607,7 +619,8 @@ int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float*
     const int hd = d / H;
     const size_t lds = 4 * ((size_t)4 * T * hd + 4 * T * T) * sizeof(float);
     MPO_CHECK(lds <= 160 * 1024, "set-transformer attention backward: T=%d, head dim %d needs %zu bytes of LDS", T, hd, lds);
-    mha_small_bwd_kernel<<<(B * H + 3) / 4, 256, lds, s>>>(qkv, p_save, d_o, dqkv, B, T, d, H);
+    if (T == 6 && hd == 32) mha_small_bwd_kernel<6, 32><<<(B * H + 3) / 4, 256, lds, s>>>(qkv, p_save, d_o, dqkv, B, T, d, H);
+    else mha_small_bwd_kernel<0, 0><<<(B * H + 3) / 4, 256, lds, s>>>(qkv, p_save, d_o, dqkv, B, T, d, H);
     MPO_LAUNCH_CHECK();
     return 0;
 }
