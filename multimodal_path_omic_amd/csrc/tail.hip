@@ -15,6 +15,10 @@ __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1
 // ------------------------------------------------------------------ LayerNorm (one wave per row)
 // Rows may belong to several BRANCHES (independent modules of identical shape batched into one launch, e.g. the
 // path and the omic set-Transformer): branch = row / rows_per_branch picks the affine parameters.
+// D4: float4 columns per lane fixed at compile time (1: d = 256, the model's width; 2: d = 512; 0: any d, strided loops).
+// The fixed-width versions read the row ONCE into registers; the strided one re-reads it for the variance and the output
+// and waits for every load of its run-time loops in turn (4.8 us -> the launch floor for 384 rows).
+template <int D4>
 __global__ void ln_fwd_kernel(const float* __restrict__ x, LnBranches p, float* __restrict__ y, float* __restrict__ stats,
                               int rows, int d, float eps) {
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -24,17 +28,49 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, LnBranches p, float* 
     const float* __restrict__ w = p.w[br];
     const float* __restrict__ b = p.b[br];
     const float* xr = x + (size_t)r * d;
-    float s = 0.f;
-    for (int c = lane; c < d; c += 64) s += xr[c];
-    const float mean = wave_sum(s) / d;
-    float v = 0.f;
-    for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; v += t * t; }
-    const float rstd = rsqrtf(wave_sum(v) / d + eps);
-    for (int c = lane; c < d; c += 64) y[(size_t)r * d + c] = (xr[c] - mean) * rstd * w[c] + b[c];
-    if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    if constexpr (D4 > 0) {
+        float4 v[D4], wv[D4], bv[D4];
+#pragma unroll
+        for (int k = 0; k < D4; ++k) {
+            v[k] = *reinterpret_cast<const float4*>(xr + (k * 64 + lane) * 4);
+            wv[k] = *reinterpret_cast<const float4*>(w + (k * 64 + lane) * 4);
+            bv[k] = *reinterpret_cast<const float4*>(b + (k * 64 + lane) * 4);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < D4; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        const float mean = wave_sum(s) / d;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < D4; ++k) {
+            v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+            q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        }
+        const float rstd = rsqrtf(wave_sum(q) / d + eps);
+#pragma unroll
+        for (int k = 0; k < D4; ++k) {
+            float4 o;
+            o.x = v[k].x * rstd * wv[k].x + bv[k].x;
+            o.y = v[k].y * rstd * wv[k].y + bv[k].y;
+            o.z = v[k].z * rstd * wv[k].z + bv[k].z;
+            o.w = v[k].w * rstd * wv[k].w + bv[k].w;
+            *reinterpret_cast<float4*>(y + (size_t)r * d + (k * 64 + lane) * 4) = o;
+        }
+        if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    } else {
+        float s = 0.f;
+        for (int c = lane; c < d; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / d;
+        float v = 0.f;
+        for (int c = lane; c < d; c += 64) { const float t = xr[c] - mean; v += t * t; }
+        const float rstd = rsqrtf(wave_sum(v) / d + eps);
+        for (int c = lane; c < d; c += 64) y[(size_t)r * d + c] = (xr[c] - mean) * rstd * w[c] + b[c];
+        if (lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w    [dx may alias dy]
+template <int D4>
 __device__ __forceinline__ void ln_bwd_rows(int rb, const float* __restrict__ dy, const float* __restrict__ x,
                                             const float* __restrict__ stats, const LnBranches& p, float* __restrict__ dx,
                                             int rows, int d, int accumulate) {
@@ -43,20 +79,53 @@ __device__ __forceinline__ void ln_bwd_rows(int rb, const float* __restrict__ dy
     const int lane = threadIdx.x & 63;
     const float* __restrict__ w = p.w[r / p.rows_per_branch];
     const float mean = stats[2 * r], rstd = stats[2 * r + 1];
-    float c1 = 0.f, c2 = 0.f;
-    for (int c = lane; c < d; c += 64) {
-        const float g = dy[(size_t)r * d + c] * w[c];
-        const float xh = (x[(size_t)r * d + c] - mean) * rstd;
-        c1 += g;
-        c2 += g * xh;
-    }
-    c1 = wave_sum(c1) / d;
-    c2 = wave_sum(c2) / d;
-    for (int c = lane; c < d; c += 64) {
-        const float g = dy[(size_t)r * d + c] * w[c];
-        const float xh = (x[(size_t)r * d + c] - mean) * rstd;
-        const float v = rstd * (g - c1 - xh * c2);
-        dx[(size_t)r * d + c] = accumulate ? dx[(size_t)r * d + c] + v : v;
+    if constexpr (D4 > 0) {
+        float g[D4][4], xh[D4][4], acc[D4][4];
+#pragma unroll
+        for (int k = 0; k < D4; ++k) {
+            const size_t at = (size_t)r * d + (k * 64 + lane) * 4;
+            const float4 gv = *reinterpret_cast<const float4*>(dy + at);
+            const float4 xv = *reinterpret_cast<const float4*>(x + at);
+            const float4 wv = *reinterpret_cast<const float4*>(w + (k * 64 + lane) * 4);
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (accumulate) av = *reinterpret_cast<const float4*>(dx + at);
+            g[k][0] = gv.x * wv.x; g[k][1] = gv.y * wv.y; g[k][2] = gv.z * wv.z; g[k][3] = gv.w * wv.w;
+            xh[k][0] = (xv.x - mean) * rstd; xh[k][1] = (xv.y - mean) * rstd;
+            xh[k][2] = (xv.z - mean) * rstd; xh[k][3] = (xv.w - mean) * rstd;
+            acc[k][0] = av.x; acc[k][1] = av.y; acc[k][2] = av.z; acc[k][3] = av.w;
+        }
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < D4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c1 += g[k][j]; c2 += g[k][j] * xh[k][j]; }
+        c1 = wave_sum(c1) / d;
+        c2 = wave_sum(c2) / d;
+#pragma unroll
+        for (int k = 0; k < D4; ++k) {
+            float4 o;
+            o.x = acc[k][0] + rstd * (g[k][0] - c1 - xh[k][0] * c2);
+            o.y = acc[k][1] + rstd * (g[k][1] - c1 - xh[k][1] * c2);
+            o.z = acc[k][2] + rstd * (g[k][2] - c1 - xh[k][2] * c2);
+            o.w = acc[k][3] + rstd * (g[k][3] - c1 - xh[k][3] * c2);
+            *reinterpret_cast<float4*>(dx + (size_t)r * d + (k * 64 + lane) * 4) = o;
+        }
+    } else {
+        float c1 = 0.f, c2 = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            const float g = dy[(size_t)r * d + c] * w[c];
+            const float xh = (x[(size_t)r * d + c] - mean) * rstd;
+            c1 += g;
+            c2 += g * xh;
+        }
+        c1 = wave_sum(c1) / d;
+        c2 = wave_sum(c2) / d;
+        for (int c = lane; c < d; c += 64) {
+            const float g = dy[(size_t)r * d + c] * w[c];
+            const float xh = (x[(size_t)r * d + c] - mean) * rstd;
+            const float v = rstd * (g - c1 - xh * c2);
+            dx[(size_t)r * d + c] = accumulate ? dx[(size_t)r * d + c] + v : v;
+        }
     }
 }
 
@@ -87,12 +156,13 @@ __device__ __forceinline__ void ln_bwd_params_cols(int cb, int br, const float* 
     }
 }
 // what: 1 = dx rows, 2 = parameter gradients, 3 = both in ONE launch (row blocks first, then column blocks)
+template <int D4>
 __global__ __launch_bounds__(256)
 void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats, LnBranches p,
                    float* __restrict__ dx, int rows, int d, int accumulate, int what) {
     const int row_blocks = (what & 1) ? (rows + 3) / 4 : 0;
     if ((int)blockIdx.x < row_blocks) {
-        ln_bwd_rows(blockIdx.x, dy, x, stats, p, dx, rows, d, accumulate);
+        ln_bwd_rows<D4>(blockIdx.x, dy, x, stats, p, dx, rows, d, accumulate);
     } else {
         const int cblocks = (d + 15) / 16, i = blockIdx.x - row_blocks;
         ln_bwd_params_cols(i % cblocks, i / cblocks, dy, x, stats, p, d);
@@ -566,11 +636,21 @@ __global__ void cag_mid_bwd_kernel(const float* __restrict__ dm, const float* __
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers
+static bool ln_al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+// the fixed-width LayerNorm kernels read the affine parameters as float4
+static bool ln_vec_ok(const LnBranches& p, bool) {
+    for (int i = 0; i < p.n; ++i)
+        if (!ln_al16(p.w[i]) || !ln_al16(p.b[i])) return false;
+    return true;
+}
 int mpo_launch_ln_fwd_br(const float* x, const LnBranches& p, float* y, float* stats, int rows, int d, float eps, hipStream_t s) {
     if (rows <= 0) return 0;
     MPO_CHECK(p.n >= 1 && p.n <= kMaxBranches && p.rows_per_branch * p.n == rows, "layer norm: %d rows over %d branches of %d",
               rows, p.n, p.rows_per_branch);
-    ln_fwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(x, p, y, stats, rows, d, eps);
+    const bool vec = ln_vec_ok(p, false) && ln_al16(x) && ln_al16(y);
+    if (vec && d == 256) ln_fwd_kernel<1><<<(rows + 3) / 4, 256, 0, s>>>(x, p, y, stats, rows, d, eps);
+    else if (vec && d == 512) ln_fwd_kernel<2><<<(rows + 3) / 4, 256, 0, s>>>(x, p, y, stats, rows, d, eps);
+    else ln_fwd_kernel<0><<<(rows + 3) / 4, 256, 0, s>>>(x, p, y, stats, rows, d, eps);
     MPO_LAUNCH_CHECK();
     return 0;
 }
@@ -580,7 +660,10 @@ int mpo_launch_ln_bwd_br(const float* dy, const float* x, const float* stats, co
     MPO_CHECK(p.n >= 1 && p.n <= kMaxBranches && p.rows_per_branch * p.n == rows, "layer norm: %d rows over %d branches of %d",
               rows, p.n, p.rows_per_branch);
     const int blocks = ((what & 1) ? (rows + 3) / 4 : 0) + ((what & 2) ? p.n * ((d + 15) / 16) : 0);
-    ln_bwd_kernel<<<blocks, 256, 0, s>>>(dy, x, stats, p, dx, rows, d, accumulate, what);
+    const bool vec = ln_vec_ok(p, false) && ln_al16(x) && ln_al16(dy) && ln_al16(dx);
+    if (vec && d == 256) ln_bwd_kernel<1><<<blocks, 256, 0, s>>>(dy, x, stats, p, dx, rows, d, accumulate, what);
+    else if (vec && d == 512) ln_bwd_kernel<2><<<blocks, 256, 0, s>>>(dy, x, stats, p, dx, rows, d, accumulate, what);
+    else ln_bwd_kernel<0><<<blocks, 256, 0, s>>>(dy, x, stats, p, dx, rows, d, accumulate, what);
     MPO_LAUNCH_CHECK();
     return 0;
 }
