@@ -264,6 +264,22 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
                          const float* saved, const float* dy, float* dx, float* const* grads,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
+/* ---- f3: self-attention over the M rows of a bag -- the attention core of `nn.MultiheadAttention(embed, num_heads)` with
+ * query = key = value = the bag (models/ge_nacagat/ge_nacagat.py:27,49: one head, the M x M map returned) and of the
+ * `nn.TransformerEncoderLayer(nhead=8)` blocks over the same rows (:30-33,53; reached through mpo_encoder_* with T > 16).
+ * qkv [n_bags][M][3 d] = the packed in_proj output (q | k | v; head h = columns h*d/heads .. of each part); out [n_bags][M][d]
+ * is the per-head context BEFORE out_proj.  saved: mpo_bag_self_attention_saved_floats() floats (one log-sum-exp per head
+ * and row -- no M x M state is kept).  attn_map (nullable, heads == 1 only) [n_bags][M][M] = softmax(q k^T / sqrt(d)).
+ * drop_p: dropout on the probabilities (realised round(256 p) / 256; regenerated in the backward from seed / offset /
+ * *rng_epoch); the map is the undropped softmax.  Head dimension d / heads in {16, 32, 64, 128, 256}.
+ * backward workspace: saved_floats * 4 bytes.  The map carries no gradient (the reference only returns it). */
+size_t mpo_bag_self_attention_saved_floats(int n_bags, int M, int heads);
+int mpo_bag_self_attention_forward(const float* qkv, int n_bags, int M, int d, int heads, float drop_p, uint64_t seed, uint64_t offset,
+                                   const uint64_t* rng_epoch, float* out, float* saved, float* attn_map, mpo_stream_t stream);
+int mpo_bag_self_attention_backward(const float* qkv, const float* out, const float* saved, const float* d_out, int n_bags, int M, int d,
+                                    int heads, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch, float* d_qkv,
+                                    void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
 /* ---- K5: gated attention-MIL pooling = AttentionNetGated (models/blocks.py:13-48) + softmax pooling + rho
  * (models/mcat/mcat.py:105-109).  x [n_slides*L, d] -> scores [n_slides*L] (raw A), h [n_slides, d].
  * 8 pointers: attention_a.0.weight, .bias, attention_b.0.weight, .bias, attention_c.weight, .bias, rho.0.weight, .bias

@@ -172,6 +172,7 @@ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, co
 // ------------------------------------------------------------------ self-attention over the T tokens of one slide
 // qkv [B*T][3d] (q | k | v), H heads of hd = d / H.  One workgroup per slide, everything through LDS.
 constexpr int kMaxT = 16;
+constexpr int kPoolLongL = 64;          // pooling axes longer than this are spread over the grid
 
 // One WAVE per (slide, head): the four waves of a workgroup take four consecutive (slide, head) pairs and never wait for
 // each other beyond the workgroup barriers between phases.  (First version: one workgroup per slide, everything for its 8
@@ -407,6 +408,101 @@ void pool_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x, 
     for (int it = tid; it < L * d; it += 256) {
         const int l = it / d, c = it % d;
         dx[((size_t)b * L + l) * d + c] = w[(size_t)b * L + l] * dhb[c];
+    }
+}
+
+// ---- the same pooling over a LONG axis (L = the M rows of a bag: models/ge_nacagat/ge_nacagat.py:56-58).  The kernels above
+// give one workgroup a whole slide and walk L serially; here L is spread over the grid.
+// w = softmax_L(scores): one workgroup of 1024 threads per slide
+__global__ __launch_bounds__(1024)
+void pool_long_softmax_kernel(const float* __restrict__ scores, float* __restrict__ w, int L) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* sc = scores + (size_t)b * L;
+    float mx = -INFINITY;
+    for (int l = tid; l < L; l += 1024) mx = fmaxf(mx, sc[l]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int l = tid; l < L; l += 1024) sum += __expf(sc[l] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += red[k];
+    const float inv = 1.0f / sum;
+    for (int l = tid; l < L; l += 1024) w[(size_t)b * L + l] = __expf(sc[l] - mx) * inv;
+}
+// h[b][c] = sum_l w[l] x[l][c]: 16 columns per workgroup, 16 row groups of 16 lanes, fixed summation order
+__global__ __launch_bounds__(256)
+void pool_long_wsum_kernel(const float* __restrict__ w, const float* __restrict__ x, float* __restrict__ h, int L, int d) {
+    __shared__ float red[16][17];
+    const int b = blockIdx.y, c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + c;
+    const float* wb = w + (size_t)b * L;
+    const float* xb = x + (size_t)b * L * d;
+    float a = 0.f;
+    if (col < d) {
+        int l = rg;
+        for (; l + 7 * 16 < L; l += 8 * 16) {
+            float wv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { wv[u] = wb[l + 16 * u]; xv[u] = xb[(size_t)(l + 16 * u) * d + col]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += wv[u] * xv[u];
+        }
+        for (; l < L; l += 16) a += wb[l] * xb[(size_t)l * d + col];
+    }
+    red[rg][c] = a;
+    __syncthreads();
+    if (rg == 0 && col < d) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][c];
+        h[(size_t)b * d + col] = t;
+    }
+}
+// dw[l] = dh . x[l] (one wave per row) -> d_scores (stash), and dx[l] = w[l] dh
+__global__ __launch_bounds__(256)
+void pool_long_rows_kernel(const float* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ w,
+                           float* __restrict__ d_scores, float* __restrict__ dx, int L, int d) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= L) return;
+    const size_t i = (size_t)b * L + l;
+    const float* dhb = dh + (size_t)b * d;
+    const float wl = w[i];
+    float a = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float g = dhb[c];
+        a += g * x[i * d + c];
+        dx[i * d + c] = wl * g;
+    }
+    a = wave_sum(a);
+    if (lane == 0) d_scores[i] = a;
+}
+// d_scores[l] = w[l] (dw[l] - sum_l' w[l'] dw[l']) + d_ext[l]
+__global__ __launch_bounds__(1024)
+void pool_long_dscore_kernel(const float* __restrict__ w, const float* __restrict__ d_ext, float* __restrict__ d_scores, int L) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float dl = 0.f;
+    for (int l = tid; l < L; l += 1024) dl += w[(size_t)b * L + l] * d_scores[(size_t)b * L + l];
+    dl = wave_sum(dl);
+    if (lane == 0) red[wv] = dl;
+    __syncthreads();
+    dl = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dl += red[k];
+    for (int l = tid; l < L; l += 1024) {
+        const size_t i = (size_t)b * L + l;
+        d_scores[i] = w[i] * (d_scores[i] - dl) + (d_ext ? d_ext[i] : 0.f);
     }
 }
 
@@ -708,13 +804,26 @@ int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float*
     return 0;
 }
 int mpo_launch_pool_fwd(const float* scores, const float* x, float* w, float* h, int B, int L, int d, hipStream_t s) {
-    pool_fwd_kernel<<<B, 256, 0, s>>>(scores, x, w, h, L, d);
+    if (L > kPoolLongL) {
+        pool_long_softmax_kernel<<<B, 1024, 0, s>>>(scores, w, L);
+        MPO_LAUNCH_CHECK();
+        pool_long_wsum_kernel<<<dim3((d + 15) / 16, B), 256, 0, s>>>(w, x, h, L, d);
+    } else {
+        pool_fwd_kernel<<<B, 256, 0, s>>>(scores, x, w, h, L, d);
+    }
     MPO_LAUNCH_CHECK();
     return 0;
 }
 int mpo_launch_pool_bwd(const float* dh, const float* x, const float* w, const float* d_ext, float* d_scores, float* dx,
                         int B, int L, int d, hipStream_t s) {
-    pool_bwd_kernel<<<B, 256, 0, s>>>(dh, x, w, d_ext, d_scores, dx, L, d);
+    if (L > kPoolLongL) {
+        MPO_CHECK(B <= 65535, "pooling over a long axis: %d slides exceed the grid", B);
+        pool_long_rows_kernel<<<dim3((L + 3) / 4, B), 256, 0, s>>>(dh, x, w, d_scores, dx, L, d);
+        MPO_LAUNCH_CHECK();
+        pool_long_dscore_kernel<<<B, 1024, 0, s>>>(w, d_ext, d_scores, L);
+    } else {
+        pool_bwd_kernel<<<B, 256, 0, s>>>(dh, x, w, d_ext, d_scores, dx, L, d);
+    }
     MPO_LAUNCH_CHECK();
     return 0;
 }

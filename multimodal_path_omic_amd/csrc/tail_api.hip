@@ -69,7 +69,11 @@ template <typename C>
 void enc_carve(C& c, EncLayerSaved* out, int B, int T, int d, int ff, int H) {
     const size_t R = (size_t)B * T;
     EncLayerSaved s;
-    s.qkv = c.take(R * 3 * d); s.psave = c.take((size_t)B * 2 * H * T * T); s.o = c.take(R * d);
+    s.qkv = c.take(R * 3 * d);
+    // attention state: the two T x T probability matrices per head of the token tail, or (T = the rows of a bag) one
+    // log-sum-exp per head and row
+    s.psave = c.take(T <= kSmallAttnMaxT ? (size_t)B * 2 * H * T * T : (size_t)B * H * T);
+    s.o = c.take(R * d);
     s.s1 = c.take(R * d); s.st1 = c.take(2 * R); s.x1 = c.take(R * d); s.f = c.take(R * ff);
     s.s2 = c.take(R * d); s.st2 = c.take(2 * R); s.x2 = c.take(R * d);
     if (out) *out = s;
@@ -164,7 +168,8 @@ int mpo_encoder_forward(const float* x, int n_branches, int n_slides, int T, int
                                    S.x1 + br * Rd, drop_br(d3, br, Rd))));
         }
         RC(q.launch(stream));
-        RC(mpo_launch_mha_small_fwd(S.qkv, S.o, S.psave, BT, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, stream));
+        if (T <= kSmallAttnMaxT) RC(mpo_launch_mha_small_fwd(S.qkv, S.o, S.psave, BT, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, stream));
+        else RC(mpo_launch_bag_sa_fwd(S.qkv, BT, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, S.o, S.psave, nullptr, stream));
         RC(o.launch(stream));
         RC(mpo_launch_ln_fwd_br(S.s1, n1, S.x1, S.st1, RT, d, 1e-5f, stream));
         RC(f1.launch(stream));
@@ -240,7 +245,14 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
         // s1 = in + drop1(o W_o^T + b_o)
         RC(pairs([&](int br) { return mpo_args_bwd_input(ds1 + br * Rd, P(br, P_OUTW), dob + br * Rd, R, d, d, 1.0f, 0, gate_rng_br(d1, br, Rd)); },
                  [&](int br) { return mpo_args_bwd_weight(ds1 + br * Rd, S[l].o + br * Rd, G(br, P_OUTW), G(br, P_OUTB), R, d, d, 1.0f, gate_rng_br(d1, br, Rd)); }));
-        RC(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, BT, T, d, heads, stream));
+        if (T <= kSmallAttnMaxT) {
+            RC(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, BT, T, d, heads, stream));
+        } else {
+            // df (RT x ff floats, consumed above) holds the per-head row sums delta [BT][heads][T]
+            MPO_CHECK(heads <= ff, "encoder backward: %d heads need a delta buffer larger than the feed-forward one (%d)", heads, ff);
+            const DropSpec d0 = stream_of(drop_p, seed, base, stride, 0, rng_epoch);
+            RC(mpo_launch_bag_sa_bwd(S[l].qkv, S[l].o, S[l].psave, dob, BT, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, dqkv, df, stream));
+        }
         // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in
         RC(pairs([&](int br) {
                      GemmArgs g;
@@ -252,6 +264,26 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
         dcur = din;
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------- f3 bag self-attention
+// The attention core of nn.MultiheadAttention over the M rows of a bag (models/ge_nacagat/ge_nacagat.py:27,49): the packed
+// projections qkv [n_bags][M][3 d] come from the caller's in_proj product, the out_proj follows on the caller's side.
+size_t mpo_bag_self_attention_saved_floats(int n_bags, int M, int heads) { return (size_t)n_bags * heads * M; }
+int mpo_bag_self_attention_forward(const float* qkv, int n_bags, int M, int d, int heads, float drop_p, uint64_t seed, uint64_t offset,
+                                   const uint64_t* rng_epoch, float* out, float* saved, float* attn_map, mpo_stream_t stream) {
+    MPO_CHECK(qkv && out && saved, "bag self-attention: NULL buffer");
+    return mpo_launch_bag_sa_fwd(qkv, n_bags, M, d, heads, drop_p, seed, offset, (const unsigned long long*)rng_epoch, out, saved,
+                                 attn_map, (hipStream_t)stream);
+}
+int mpo_bag_self_attention_backward(const float* qkv, const float* out, const float* saved, const float* d_out, int n_bags, int M, int d,
+                                    int heads, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch, float* d_qkv,
+                                    void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    MPO_CHECK(qkv && out && saved && d_out && d_qkv, "bag self-attention backward: NULL buffer");
+    MPO_CHECK(workspace && workspace_bytes >= mpo_bag_self_attention_saved_floats(n_bags, M, heads) * sizeof(float),
+              "bag self-attention backward: workspace too small (%zu bytes)", workspace_bytes);
+    return mpo_launch_bag_sa_bwd(qkv, out, saved, d_out, n_bags, M, d, heads, drop_p, seed, offset, (const unsigned long long*)rng_epoch,
+                                 d_qkv, static_cast<float*>(workspace), (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------- K5 gated pooling

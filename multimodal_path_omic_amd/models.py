@@ -1,4 +1,4 @@
-"""The two models of the hot path, composed from the drop-in layers (host composition = row H1 of
+"""The models of the hot path, composed from the drop-in layers (host composition = row H1 of
 SURVEY.md section 8(a)).  Class names, constructor arguments, attribute names (= state_dict keys) and
 forward() signatures follow models/mcat/mcat.py:12-142 and models/nacagat/nacagat.py:9-138, so a
 reference checkpoint loads with load_state_dict(strict=True) and the reference's train/validate/test
@@ -210,3 +210,45 @@ class NarrowContextualAttentionGateTransformer(_FusionModelBase):
 
     def forward(self, wsi, omics):
         return self._forward_one(wsi, omics, True)
+
+
+class GeneExprNarrowContextualAttentionGateTransformer(nn.Module):
+    """Row f3: the gene-expression model of models/ge_nacagat/ge_nacagat.py:9-72 -- patch layer, ONE-head self-attention
+    over the M patch rows with its M x M map returned, the 2-layer / 8-head set-Transformer over the same M rows, gated
+    attention-MIL pooling over L = M, rho, classifier, softmax.  Constructor, attribute names (= state_dict keys) and
+    forward() follow the reference; `bag_dtype` is this package's storage switch for the patch matrix.
+
+    Long-axis pieces: ops.bag_self_attention (no M x M state except the returned map), the encoder and the pooling head
+    of the 6-token tail called with T = L = M (csrc/tail_api.hip picks the long-axis kernels)."""
+
+    def __init__(self, model_size: str = "medium", n_classes: int = 3, dropout: float = 0.25,
+                 bag_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        self.model_sizes = MODEL_SIZES[model_size]
+        d0, d1 = self.model_sizes
+        self.bag_dtype = bag_dtype
+        self.H = nn.Sequential(nn.Linear(1024, d0), nn.ReLU(), nn.Dropout(dropout))
+        self.self_attention = nn.MultiheadAttention(embed_dim=d1, num_heads=1)      # parameter holder
+        self.path_transformer = make_set_transformer(d1, dropout)
+        self.path_attention_head = AttentionNetGated(n_classes=1, input_dim=d1, hidden_dim=d1)
+        self.path_rho = nn.Sequential(nn.Linear(d1, d1), nn.ReLU(), nn.Dropout(dropout))
+        self.classifier = nn.Linear(d1, n_classes)
+
+    _patch_fc = _FusionModelBase._patch_fc
+    _fused_bag_gate = False
+
+    def forward(self, wsi):
+        """wsi (M, 1024) or (1, M, 1024) -> Y (n_classes,), {'attn': (M, M), 'path': (1, M)}   (ge_nacagat.py:43-72)."""
+        x = wsi.squeeze(0) if wsi.dim() == 3 else wsi
+        if x.dtype != self.bag_dtype:
+            x = x.to(self.bag_dtype)
+        h_bag = self._patch_fc(BagBatch.from_list([x])).data.float()
+        h_coattn, a_coattn = ops.bag_self_attention(h_bag, self.self_attention, self.training, need_weights=True)
+        path_trans = self.path_transformer(h_coattn)
+        a_path, h_path = ops.gated_pool(path_trans.unsqueeze(0), self.path_attention_head, self.path_rho, self.training)
+        logits = ops.linear(h_path, self.classifier.weight, self.classifier.bias)[0]
+        y = torch.softmax(logits, dim=0)          # F.softmax without dim on a vector (ge_nacagat.py:67)
+        return y, {"attn": a_coattn, "path": a_path[0]}
+
+    def get_trainable_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)

@@ -685,6 +685,60 @@ def encoder_stacked(x, layer_stacks, training: bool):
     return y.view(nb, b, t, d)
 
 
+class BagSelfAttentionFn(torch.autograd.Function):
+    """f3: the attention core of nn.MultiheadAttention with query = key = value = the M rows of a bag
+    (models/ge_nacagat/ge_nacagat.py:27,49), one C-ABI call each way; no M x M state is kept between them."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads: int, drop_p: float, need_map: bool):
+        lib = L.lib()
+        n_bags, m, d3 = qkv.shape
+        d = d3 // 3
+        qkv = qkv.contiguous()
+        out = torch.empty((n_bags, m, d), device=qkv.device, dtype=torch.float32)
+        saved = torch.empty(lib.mpo_bag_self_attention_saved_floats(n_bags, m, heads), device=qkv.device, dtype=torch.float32)
+        amap = torch.empty((n_bags, m, m), device=qkv.device, dtype=torch.float32) if need_map else None
+        seed, off = _reserve(1) if drop_p > 0 else (0, 0)
+        L.check(lib.mpo_bag_self_attention_forward(L.ptr(qkv), n_bags, m, d, heads, float(drop_p), seed, off, _epoch(), L.ptr(out),
+                                                   L.ptr(saved), L.ptr(amap), L.stream_of(qkv)), "mpo_bag_self_attention_forward")
+        ctx.save_for_backward(qkv, out, saved)
+        ctx.geom, ctx.drop = (n_bags, m, d, heads), (float(drop_p), seed, off)
+        if amap is not None:
+            ctx.mark_non_differentiable(amap)       # the reference returns the map and never differentiates it
+        return out, amap
+
+    @staticmethod
+    def backward(ctx, d_out, _d_map):
+        lib = L.lib()
+        qkv, out, saved = ctx.saved_tensors
+        n_bags, m, d, heads = ctx.geom
+        drop_p, seed, off = ctx.drop
+        d_qkv = torch.empty_like(qkv)
+        ws = _workspace(saved.numel() * 4, qkv.device)
+        d_out = d_out.contiguous()
+        L.check(lib.mpo_bag_self_attention_backward(L.ptr(qkv), L.ptr(out), L.ptr(saved), L.ptr(d_out), n_bags, m, d, heads, drop_p,
+                                                    seed, off, _epoch(), L.ptr(d_qkv), L.ptr(ws), ws.numel(), L.stream_of(qkv)),
+                "mpo_bag_self_attention_backward")
+        return d_qkv, None, None, None
+
+
+def bag_self_attention(x, mha, training: bool, need_weights: bool = True):
+    """x (M, d) or (n_bags, M, d) through the parameters of an nn.MultiheadAttention `mha` as self-attention
+    (query = key = value = x) -> (output, map averaged over heads | None) like mha(x, x, x).  The in / out projections are
+    plain GEMMs over M rows; the attention itself is bag_selfattn.hip."""
+    if mha.in_proj_weight is None or mha.bias_k is not None or mha.add_zero_attn:
+        raise NotImplementedError("bag self-attention: packed in_proj, no bias_k / zero-attn (the reference's constructor)")
+    if need_weights and mha.num_heads != 1:
+        raise NotImplementedError("bag self-attention: the M x M map is returned for one head (models/ge_nacagat/ge_nacagat.py:27)")
+    xb = x if x.dim() == 3 else x.unsqueeze(0)
+    qkv = F.linear(xb.float(), mha.in_proj_weight, mha.in_proj_bias)
+    out, amap = BagSelfAttentionFn.apply(qkv, mha.num_heads, mha.dropout if training else 0.0, bool(need_weights))
+    out = F.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    if x.dim() == 2:
+        out, amap = out[0], (amap[0] if amap is not None else None)
+    return out, amap
+
+
 class GatedPoolFn(torch.autograd.Function):
     """K5: gated attention-MIL scorer + softmax pooling + rho, one C-ABI call each way."""
 

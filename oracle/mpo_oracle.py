@@ -259,6 +259,35 @@ def nacagat_forward(p, wsi, omics, bag_storage=None, round_gemm_out=False):
     return _tail(h_co, g_bag, a_co, p)
 
 
+# --------------------------------------------------------------------------- f3
+def bag_self_attention(x, p, prefix="self_attention", nhead=1):
+    """nn.MultiheadAttention(embed, num_heads)(x, x, x) on the unbatched (M, d) bag, dropout off
+    (models/ge_nacagat/ge_nacagat.py:27,49).  Returns (output (M, d), map averaged over heads (M, M))."""
+    m, d = x.shape
+    hd = d // nhead
+    qkv = x @ p[prefix + ".in_proj_weight"].t() + p[prefix + ".in_proj_bias"]
+    q, k, v = (qkv[:, i * d:(i + 1) * d].reshape(m, nhead, hd).transpose(0, 1) for i in range(3))   # (h, M, hd)
+    a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(hd), dim=-1)                                 # (h, M, M)
+    o = (a @ v).transpose(0, 1).reshape(m, d)
+    return _lin(o, p, prefix + ".out_proj"), a.mean(0)
+
+
+def ge_nacagat_forward(p, wsi, bag_storage=None, round_gemm_out=False):
+    """GeneExprNarrowContextualAttentionGateTransformer.forward, models/ge_nacagat/ge_nacagat.py:43-72 (eval mode):
+    Y (n_classes,) = softmax over the classifier logits, {'attn': (M, M), 'path': (1, M) raw pooling scores}."""
+    h_bag = patch_fc(wsi, p, storage=bag_storage, round_gemm_out=round_gemm_out)
+    h_co, a_co = bag_self_attention(h_bag, p)
+    path = set_transformer(h_co, p, "path_transformer")
+    a_path, h_path = gated_mil_pool(path, p, "path_attention_head", "path_rho")
+    logits = _lin(h_path, p, "classifier")
+    return torch.softmax(logits, dim=0), {"attn": a_co, "path": a_path}
+
+
+def ge_ce_loss(y, target):
+    """models/ge_nacagat/main.py:33 -- nn.CrossEntropyLoss applied to the ALREADY soft-maxed Y (the reference's quirk)."""
+    return F.cross_entropy(y.unsqueeze(0), target.reshape(1).long())
+
+
 # --------------------------------------------------------------------------- H9
 def ces_loss(hazards, survs, y, c, alpha=0.75, eps=1e-7):
     """CrossEntropySurvivalLoss, models/loss.py:5-28 (batch of one slide)."""

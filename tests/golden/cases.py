@@ -115,6 +115,26 @@ MODEL_CASES = {
 }
 
 
+def ge_model_shapes(d=E, n_classes=3):
+    """state_dict of the gene-expression model in registration order (models/ge_nacagat/ge_nacagat.py:19-41)."""
+    s = {"H.0.weight": (d, 1024), "H.0.bias": (d,),
+         "self_attention.in_proj_weight": (3 * d, d), "self_attention.in_proj_bias": (3 * d,),
+         "self_attention.out_proj.weight": (d, d), "self_attention.out_proj.bias": (d,)}
+    s.update(encoder_shapes("path_transformer"))
+    s.update(pool_shapes("path_attention_head", "path_rho"))
+    s.update({"classifier.weight": (n_classes, d), "classifier.bias": (n_classes,)})
+    return s
+
+
+# row f3: name -> (M, seed).  3000 is the size of the reference's own smoke test (ge_nacagat.py:82); 333 is ragged against
+# every tile size of the kernels.
+GE_MODEL_CASES = {"ge_m333": (333, 431), "ge_m3000": (3000, 432)}
+
+
+def ge_model_inputs(m, seed):
+    return syn.make_bag(m, seed), torch.tensor([seed % 3])
+
+
 # ------------------------------------------------------------------ input builders
 def coattn_inputs(m, seed):
     """query (6,E) and an H_bag-like bag (M,E): ReLU'd normal, ~50 % zeros."""

@@ -42,6 +42,8 @@ from models.fusion import ConcatFusion                                    # noqa
 from models.loss import CrossEntropySurvivalLoss, CrossEntropySurvivalAttnRegLoss  # noqa: E402
 from mcat import MultimodalCoAttentionTransformer                          # noqa: E402
 from nacagat import NarrowContextualAttentionGateTransformer               # noqa: E402
+sys.path.insert(0, f"{REF}/models/ge_nacagat")
+from ge_nacagat import GeneExprNarrowContextualAttentionGateTransformer    # noqa: E402
 
 import cases as C                                                          # noqa: E402
 from multimodal_path_omic_amd import synthetic as syn                      # noqa: E402
@@ -275,6 +277,32 @@ def gen_models():
     save("models", out)
 
 
+# ----------------------------------------------------------------------------- f3
+def gen_ge_models():
+    """models/ge_nacagat/ge_nacagat.py:43-72 in eval mode + the loss of models/ge_nacagat/main.py:33 (CrossEntropyLoss on
+    the soft-maxed Y) and its parameter gradients."""
+    out = {}
+    ce = nn.CrossEntropyLoss()
+    for case, (m, seed) in C.GE_MODEL_CASES.items():
+        model = GeneExprNarrowContextualAttentionGateTransformer(model_size="medium").eval()
+        shapes = C.ge_model_shapes()
+        ref_shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        assert ref_shapes == shapes and list(ref_shapes) == list(shapes), "cases.ge_model_shapes drifted from the reference"
+        model.load_state_dict(syn.fill_state_dict(shapes, seed), strict=True)
+        wsi, target = C.ge_model_inputs(m, seed + 1)
+        y, att = model(wsi=wsi)
+        assert y.shape == (3,) and att["attn"].shape == (m, m) and att["path"].shape == (1, m)
+        loss = ce(y.unsqueeze(0), target)
+        gs = grads_of(loss, list(model.named_parameters()))
+        out[f"{case}/Y"], out[f"{case}/A_path"], out[f"{case}/loss"] = y, att["path"], loss
+        out[f"{case}/A_attn_sub"] = sub(att["attn"])
+        out[f"{case}/A_attn_rowmax"] = att["attn"].max(dim=1).values
+        out[f"{case}/A_attn_diag"] = att["attn"].diagonal()
+        for n, g in gs.items():
+            out[f"{case}/grad/{n}"] = sub(g, 256)
+    save("ge_models", out)
+
+
 # ----------------------------------------------------------------------------- H9
 def gen_loss():
     ces = CrossEntropySurvivalLoss()
@@ -332,6 +360,6 @@ def gen_cohort():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["coattn_mcat", "coattn_nacagat", "cag", "encoder", "pool", "fusion",
-                             "models", "loss", "cohort", "fusion_next"]
+                             "models", "loss", "cohort", "fusion_next", "ge_models"]
     for w in which:
         globals()["gen_" + w]()

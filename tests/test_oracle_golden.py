@@ -203,3 +203,26 @@ def test_fusion_next_rows(golden, kind):
     for n, gr in grads((y * probe).sum(), named).items():
         ref = g[f"{kind}/grad/{n}"]
         close(sub(gr), ref, rtol=1e-3, atol=2e-5 * max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("case", list(C.GE_MODEL_CASES))
+def test_ge_model(golden, case):
+    """Row f3: the gene-expression model (models/ge_nacagat/ge_nacagat.py) and the loss of its training loop."""
+    g = golden("ge_models")
+    m, seed = C.GE_MODEL_CASES[case]
+    p = leafify(syn.fill_state_dict(C.ge_model_shapes(), seed))
+    wsi, target = C.ge_model_inputs(m, seed + 1)
+    y, att = O.ge_nacagat_forward(p, wsi)
+    y_b, _ = O.ge_nacagat_forward(p, wsi.unsqueeze(0))
+    close(y, y_b, rtol=1e-5, atol=1e-6)
+    assert att["attn"].shape == (m, m) and att["path"].shape == (1, m)
+    close(y, g[f"{case}/Y"], rtol=1e-4, atol=2e-5)
+    close(att["path"], g[f"{case}/A_path"], rtol=1e-3, atol=1e-4)
+    close(sub(att["attn"]), g[f"{case}/A_attn_sub"], rtol=2e-3, atol=1e-9)
+    close(att["attn"].max(dim=1).values, g[f"{case}/A_attn_rowmax"], rtol=2e-3, atol=1e-9)
+    close(att["attn"].diagonal(), g[f"{case}/A_attn_diag"], rtol=2e-3, atol=1e-9)
+    loss = O.ge_ce_loss(y, target)
+    close(loss, g[f"{case}/loss"], rtol=1e-4, atol=1e-5)
+    for n, gr in grads(loss, list(p.items())).items():
+        ref = g[f"{case}/grad/{n}"]
+        close(sub(gr, 256), ref, rtol=5e-3, atol=1e-4 * max(1e-3, float(ref.abs().max())))
