@@ -359,6 +359,54 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
     return out
 
 
+def ge_extra(dev, patches=15000, steps=5):
+    """Row f3 as an extra: the gene-expression model (models/ge_nacagat/ge_nacagat.py) on one 15 000 x 1024 bf16 bag per step, as
+    the reference's loop feeds it (models/ge_nacagat/main.py:25-52): forward, CrossEntropyLoss on Y, backward -- training
+    mode, every dropout on.  Roofline: the 8-head attention forward over the M rows (fp32 MFMA bound)."""
+    import torch
+    from multimodal_path_omic_amd import ops, synthetic as syn
+    from multimodal_path_omic_amd.models import GeneExprNarrowContextualAttentionGateTransformer
+    torch.manual_seed(0)
+    model = GeneExprNarrowContextualAttentionGateTransformer(bag_dtype=torch.bfloat16).to(dev).train()
+    wsi = syn.make_bag(patches, 77).to(dev).to(torch.bfloat16)
+    target = torch.tensor([1], device=dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        y, _ = model(wsi=wsi)
+        torch.nn.functional.cross_entropy(y.unsqueeze(0), target).backward()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    heads, d = 8, 256
+    qkv = torch.randn(1, patches, 3 * d, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
+    with torch.no_grad():
+        for a_, b_ in ev:
+            a_.record()
+            ops.BagSelfAttentionFn.apply(qkv, heads, 0.25, False)
+            b_.record()
+    torch.cuda.synchronize(dev)
+    us = [a_.elapsed_time(b_) * 1e3 for a_, b_ in ev[1:]]
+    flops = 2 * 2.0 * patches * patches * d                       # scores + context, all heads
+    avg = sum(us) / len(us)
+    del model, wsi, qkv
+    return {"metric": "slides/sec (fwd+bwd) at 15k-patch bags", "value": round(1e3 / ms, 2), "unit": "slides/s", "n_gpus": 1,
+            "steps": steps, "ms_per_step": round(ms, 2), "dtype": "f32 attention / bf16 bag", "data": "synthetic",
+            "config": {"workload": f"GE-NACAGAT medium fwd+CE+bwd, one {patches}x1024 bf16 bag per step, M x M map returned",
+                       "launch": "eager"},
+            "roofline": {"bound": "mfma", "kernel": "bag_sa_fwd_kernel<32> (8 heads, dropout 0.25, fp32 MFMA)",
+                         "achieved": round(flops / avg / 1e6, 2), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(flops / avg / 1e6 / 157.3, 4), "traffic": None, "flops_per_launch": flops,
+                         "avg_launch_us": round(avg, 1), "min_launch_us": round(min(us), 1), "launches_timed": len(us)}}
+
+
 def extras(a, dev, rank, world):
     """The other BASELINE configs as `extra` entries of the same line: cfg 4 (ragged windows; at every N, it is the
     data-parallel config), and at N = 1 also cfg 3 (NaCAGaT) and cfg 5 (100k-patch fp32 bags, window 8)."""
@@ -375,6 +423,11 @@ def extras(a, dev, rank, world):
             r = {"error": f"{type(e).__name__}: {str(e)[:200]}"} if rank == 0 else None
         if rank == 0:
             out[name] = r
+    if world == 1:
+        try:
+            out["f3_ge_nacagat_15k"] = ge_extra(dev)
+        except Exception as e:
+            out["f3_ge_nacagat_15k"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     return out
 
 

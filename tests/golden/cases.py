@@ -120,8 +120,8 @@ def ge_model_shapes(d=E, n_classes=3):
     s = {"H.0.weight": (d, 1024), "H.0.bias": (d,),
          "self_attention.in_proj_weight": (3 * d, d), "self_attention.in_proj_bias": (3 * d,),
          "self_attention.out_proj.weight": (d, d), "self_attention.out_proj.bias": (d,)}
-    s.update(encoder_shapes("path_transformer"))
-    s.update(pool_shapes("path_attention_head", "path_rho"))
+    s.update(encoder_shapes("path_transformer", d=d))
+    s.update(pool_shapes("path_attention_head", "path_rho", d=d))
     s.update({"classifier.weight": (n_classes, d), "classifier.bias": (n_classes,)})
     return s
 

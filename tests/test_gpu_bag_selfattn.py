@@ -243,3 +243,30 @@ def test_ge_model_training_step_at_15000_rows(dev):
     for n, prm in model.named_parameters():
         assert prm.grad is not None and bool(torch.isfinite(prm.grad).all()), n
         assert float(prm.grad.abs().max()) > 0, n
+
+
+def test_ge_model_small_equals_oracle_and_big_is_refused(dev):
+    """model_size='small' (embed 128: head dimensions 128 and 16) against the oracle; 'big' (one head of 512) is refused by
+    the attention kernels with a message, not run some other way."""
+    m, seed = 300, 4545
+    shapes = C.ge_model_shapes(d=128)
+    sd = syn.fill_state_dict(shapes, seed)
+    model = GeneExprNarrowContextualAttentionGateTransformer(model_size="small")
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    wsi, target = C.ge_model_inputs(m, seed + 1)
+    y, att = model(wsi=wsi.to(dev))
+    p = _leaf(sd)
+    yo, atto = O.ge_nacagat_forward(p, wsi)
+    assert float((y.detach().cpu() - yo).abs().max()) < 1e-4
+    assert relmax(att["path"], atto["path"]) < 1e-3
+    assert ((att["attn"].cpu() - atto["attn"]).abs() / atto["attn"].clamp_min(1e-30)).max().item() < 2e-3
+    torch.nn.functional.cross_entropy(y.unsqueeze(0), target.to(dev)).backward()
+    O.ge_ce_loss(yo, target).backward()
+    for n, prm in model.named_parameters():
+        ref = p[n].grad
+        scale = max(float(ref.abs().max()), 1e-5)
+        assert float((prm.grad.cpu() - ref).abs().max()) / scale < 5e-3, n
+    big = GeneExprNarrowContextualAttentionGateTransformer(model_size="big").to(dev).eval()
+    with pytest.raises(RuntimeError, match="head dimension 512"):
+        big(wsi=wsi.to(dev))

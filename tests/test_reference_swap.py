@@ -75,6 +75,22 @@ for kind in ("mcat", "nacagat"):
         res = whole.load_state_dict(before, strict=(fusion != "gated_concat"))
         assert not res.unexpected_keys and all(k.startswith("fusion_layer.gates.") for k in res.missing_keys)
         print("ok", kind, fusion, len(before))
+
+# row f3: the gene-expression model (models/ge_nacagat/ge_nacagat.py) -- its slots and the whole model
+sys.path.insert(0, REF + "/models/ge_nacagat")
+import ge_nacagat
+for size, dd in (("small", 128), ("medium", 256), ("big", 512)):
+    torch.manual_seed(0)
+    ref = ge_nacagat.GeneExprNarrowContextualAttentionGateTransformer(model_size=size)
+    before = {k: v.clone() for k, v in ref.state_dict().items()}
+    swap(ref, "path_transformer", make_set_transformer(dd, dropout=0.25))
+    swap(ref, "path_attention_head", AttentionNetGated(n_classes=1, input_dim=dd, hidden_dim=dd))
+    after = ref.state_dict()
+    assert list(after) == list(before) and all(torch.equal(before[k], after[k]) for k in before)
+    whole = ours.GeneExprNarrowContextualAttentionGateTransformer(model_size=size)
+    whole.load_state_dict(before, strict=True)
+    assert list(whole.state_dict()) == list(before)
+    print("ok", "ge_nacagat", size, len(before))
 """
 
 
@@ -84,4 +100,4 @@ def test_every_slot_swaps_into_the_reference_models():
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, "-c", SCRIPT, REF, ROOT], capture_output=True, text=True, env=env, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok ") == 6, r.stdout
+    assert r.stdout.count("ok ") == 9, r.stdout
