@@ -246,8 +246,8 @@ def test_ge_model_training_step_at_15000_rows(dev):
 
 
 def test_ge_model_small_equals_oracle_and_big_is_refused(dev):
-    """model_size='small' (embed 128: head dimensions 128 and 16) against the oracle; 'big' (one head of 512) is refused by
-    the attention kernels with a message, not run some other way."""
+    """model_size='small' (embed 128: head dimensions 128 and 16) against the oracle; 'big' (one head of 512) is refused at
+    construction, and by the attention kernels with a message -- not run some other way."""
     m, seed = 300, 4545
     shapes = C.ge_model_shapes(d=128)
     sd = syn.fill_state_dict(shapes, seed)
@@ -267,6 +267,8 @@ def test_ge_model_small_equals_oracle_and_big_is_refused(dev):
         ref = p[n].grad
         scale = max(float(ref.abs().max()), 1e-5)
         assert float((prm.grad.cpu() - ref).abs().max()) / scale < 5e-3, n
-    big = GeneExprNarrowContextualAttentionGateTransformer(model_size="big").to(dev).eval()
+    with pytest.raises(NotImplementedError, match="big"):
+        GeneExprNarrowContextualAttentionGateTransformer(model_size="big")
+    qkv = torch.zeros(1, 32, 3 * 512, device=dev)
     with pytest.raises(RuntimeError, match="head dimension 512"):
-        big(wsi=wsi.to(dev))
+        ops.BagSelfAttentionFn.apply(qkv, 1, 0.0, True)
