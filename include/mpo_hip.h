@@ -272,8 +272,13 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
  * and row -- no M x M state is kept).  attn_map (nullable, heads == 1 only) [n_bags][M][M] = softmax(q k^T / sqrt(d)).
  * drop_p: dropout on the probabilities (realised round(256 p) / 256; regenerated in the backward from seed / offset /
  * *rng_epoch); the map is the undropped softmax.  Head dimension d / heads in {16, 32, 64, 128, 256}.
- * backward workspace: saved_floats * 4 bytes.  The map carries no gradient (the reference only returns it). */
-size_t mpo_bag_self_attention_saved_floats(int n_bags, int M, int heads);
+ * Several heads of width 32 (the encoder layers) run on bf16 MFMAs with every operand split into hi + lo (three products
+ * per term: ~16 mantissa bits); the forward then also stores the operands' bf16 forms in `saved` for the backward.
+ * mpo_set_bag_self_attention_bf16x3(0) keeps that geometry on the fp32 kernels as well (verification hook; returns the
+ * previous setting, default 1).  The map carries no gradient (the reference only returns it). */
+size_t mpo_bag_self_attention_saved_floats(int n_bags, int M, int d, int heads);
+size_t mpo_bag_self_attention_workspace_bytes(int n_bags, int M, int d, int heads);
+int mpo_set_bag_self_attention_bf16x3(int enabled);
 int mpo_bag_self_attention_forward(const float* qkv, int n_bags, int M, int d, int heads, float drop_p, uint64_t seed, uint64_t offset,
                                    const uint64_t* rng_epoch, float* out, float* saved, float* attn_map, mpo_stream_t stream);
 int mpo_bag_self_attention_backward(const float* qkv, const float* out, const float* saved, const float* d_out, int n_bags, int M, int d,

@@ -79,7 +79,9 @@ _SIGNATURES = {
     "mpo_encoder_rng_span": (c_uint64, [c_int] * 5),
     "mpo_encoder_forward": (c_int, [_P] + [c_int] * 7 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P]),
     "mpo_encoder_backward": (c_int, [_P] + [c_int] * 7 + [_P, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "mpo_bag_self_attention_saved_floats": (c_size_t, [c_int] * 3),
+    "mpo_bag_self_attention_saved_floats": (c_size_t, [c_int] * 4),
+    "mpo_bag_self_attention_workspace_bytes": (c_size_t, [c_int] * 4),
+    "mpo_set_bag_self_attention_bf16x3": (c_int, [c_int]),
     "mpo_bag_self_attention_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P]),
     "mpo_bag_self_attention_backward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_uint64, _P, _P, _P, c_size_t, _P]),
     "mpo_gated_pool_saved_floats": (c_size_t, [c_int] * 3),

@@ -398,20 +398,400 @@ int sa_backward(const float* qkv, const float* o, const float* lse2, const float
     MPO_LAUNCH_CHECK();
     return 0;
 }
+// ================================================================================================ three-term bf16 path
+// Head dimension 32 with several heads (the encoder layers: no map is returned, so the bar is the model output's, not the
+// map's): every operand is split x = hi + lo into two bf16 and each product runs as hi*hi + lo*hi + hi*lo on
+// v_mfma_f32_16x16x32_bf16 -- one instruction covers the whole head dimension (scores) or 32 keys (second products), three
+// of them cost 48 cycles against 256 for the eight fp32 instructions of the same tile.  ~16 mantissa bits per operand.
+// A split pass writes each operand once in the two forms the kernels read, so every tile load is a contiguous 4-KiB copy:
+//   row form  R[head][Mp][32]               (A operand of a score product, or a wave's own rows as B operand)
+//   T form    T[head][Mp / 32][32 c][32 p]  (A operand of a second product: for column c the 32 rows of a group in MFMA
+//             k-slot order p = 8 kk + 4 u + e  <->  row 16 u + 4 kk + e, i.e. the order in which a lane holds two
+//             consecutive score tiles' results)
+// Mp = M rounded up to 64, padding rows zero.  The same transposed-tile scheme as the fp32 kernels above otherwise.
+constexpr int kB3Ld = 40;                                  // bf16 per LDS row: 64 data bytes + 16 pad (conflict-free b128 reads)
+constexpr int kB3Tile = 64 * kB3Ld;                        // one 64-row (or 2 x 32-column) tile, in bf16 elements
+bool g_sa_b3 = true;
+
+struct B3Form { const __bf16 *rh, *rl, *th, *tl; };
+
+__device__ __forceinline__ f32x4 mma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    return acc;
+}
+// 4 KiB of a form (64 rows x 64 B, contiguous) -> LDS rows of 80 B
+__device__ __forceinline__ void b3_load(__bf16* tile, const __bf16* __restrict__ src) {
+    const uint4 v = reinterpret_cast<const uint4*>(src)[threadIdx.x];
+    *reinterpret_cast<uint4*>(tile + (threadIdx.x >> 2) * kB3Ld + (threadIdx.x & 3) * 8) = v;
+}
+__device__ __forceinline__ bf16x8 b3_frag(const __bf16* tile, int row, int kk) {
+    return *reinterpret_cast<const bf16x8*>(tile + row * kB3Ld + 8 * kk);
+}
+// two consecutive result tiles of a lane (rows 4 kk + e of tile 2g, then of tile 2g + 1) -> the B operand of a second product
+__device__ __forceinline__ void b3_split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 h, l;
+        split_bf16(a[e], h, l); hi[e] = h; lo[e] = l;
+        split_bf16(b[e], h, l); hi[4 + e] = h; lo[4 + e] = l;
+    }
+}
+__device__ __forceinline__ uint32_t pick4(const uint32_t (&v)[4], int i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
+// forward / dQ orientation (lane column = query q, four key tiles t): the four lanes of a quad share q / 4, so each draws
+// the block of ONE tile (t = its quad position) and the quad exchanges words: w[t] = word (q % 4) of tile t's block
+__device__ __forceinline__ void b3_words_q(const SaDrop& dr, int q, int n0, int kk, int lane, uint32_t (&w)[4]) {
+    const int lq = lane & 3;
+    const uint4 b = sa_block(dr, q >> 2, (n0 + 16 * lq + 4 * kk) >> 2);
+    const uint32_t own[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const uint32_t got = (uint32_t)__shfl_xor((int)pick4(own, lq ^ x), x);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t == (lq ^ x)) w[t] = got;
+    }
+}
+// dK/dV orientation (lane column = key, four query tiles t, all four words of a block used by every lane of the quad):
+// quad lane t draws tile t's block, the quad reads it from there
+__device__ __forceinline__ void b3_blocks_key(const SaDrop& dr, int key, int q0, int kk, int lane, uint32_t (&w)[4][4]) {
+    const int lq = lane & 3;
+    const uint4 b = sa_block(dr, (q0 + 16 * lq + 4 * kk) >> 2, key >> 2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int from = (lane & ~3) | t;
+        w[t][0] = (uint32_t)__shfl((int)b.x, from); w[t][1] = (uint32_t)__shfl((int)b.y, from);
+        w[t][2] = (uint32_t)__shfl((int)b.z, from); w[t][3] = (uint32_t)__shfl((int)b.w, from);
+    }
+}
+
+// src columns [col0 + 32 h, +32) of rows [32 bx, +32) -> row and / or T form (either pointer pair may be null)
+__global__ __launch_bounds__(256)
+void sa_b3_split_kernel(const float* __restrict__ src, int ld, int col0, int M, int Mp, __bf16* __restrict__ rh, __bf16* __restrict__ rl,
+                        __bf16* __restrict__ th, __bf16* __restrict__ tl) {
+    __shared__ __bf16 sh[2][32][36];
+    const int h = blockIdx.y, H = gridDim.y, seq = blockIdx.z;
+    const int rho = threadIdx.x >> 3, c4 = threadIdx.x & 7, row = blockIdx.x * 32 + rho;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < M) v = *reinterpret_cast<const float4*>(src + ((size_t)seq * M + row) * ld + col0 + 32 * h + 4 * c4);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { __bf16 a, b; split_bf16(x[e], a, b); hi[e] = a; lo[e] = b; }
+    const size_t head = (size_t)seq * H + h;
+    if (rh) {
+        const size_t at = (head * Mp + row) * 32 + 4 * c4;
+        *reinterpret_cast<bf16x4*>(rh + at) = hi;
+        *reinterpret_cast<bf16x4*>(rl + at) = lo;
+    }
+    if (th) {
+        const int slot = ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);          // rho = 16 u + 4 kk + e
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sh[0][4 * c4 + e][slot] = hi[e]; sh[1][4 * c4 + e][slot] = lo[e]; }
+        __syncthreads();
+        const int c = threadIdx.x >> 3, p4 = (threadIdx.x & 7) * 4;
+        const size_t at = ((head * (Mp / 32) + blockIdx.x) * 32 + c) * 32 + p4;
+        bf16x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { oh[e] = sh[0][c][p4 + e]; ol[e] = sh[1][c][p4 + e]; }
+        *reinterpret_cast<bf16x4*>(th + at) = oh;
+        *reinterpret_cast<bf16x4*>(tl + at) = ol;
+    }
+}
+
+// grid (Mp / 64, heads, sequences); Q, K in row form, V in T form
+__global__ __launch_bounds__(64 * kSaWaves)
+void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, float* __restrict__ lse2, int M, int Mp, int d, float scale,
+                          float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch) {
+    __shared__ __attribute__((aligned(16))) __bf16 sm[4 * kB3Tile];
+    __bf16 *kh = sm, *kl = sm + kB3Tile, *vh = sm + 2 * kB3Tile, *vl = sm + 3 * kB3Tile;
+    const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
+    const size_t head = (size_t)seq * H + h, hoff = head * Mp * 32;
+    o += (size_t)seq * M * d;
+    lse2 += head * M;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    const int q = blockIdx.x * 64 + 16 * wv + j;
+    const SaDrop dr = sa_drop(drop_p, seed, offset, epoch, (int)head);
+    const bf16x8 qh = *reinterpret_cast<const bf16x8*>(Q.rh + hoff + (size_t)q * 32 + 8 * kk);
+    const bf16x8 ql = *reinterpret_cast<const bf16x8*>(Q.rl + hoff + (size_t)q * 32 + 8 * kk);
+    const float c2 = scale * kLog2e;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float m = -INFINITY, l = 0.f;
+    for (int n0 = 0; n0 < M; n0 += 64) {
+        __syncthreads();
+        b3_load(kh, K.rh + hoff + (size_t)n0 * 32);
+        b3_load(kl, K.rl + hoff + (size_t)n0 * 32);
+        b3_load(vh, V.th + hoff + (size_t)n0 * 32);
+        b3_load(vl, V.tl + hoff + (size_t)n0 * 32);
+        __syncthreads();
+        f32x4 s[4];
+        float mx = m;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = mma3(b3_frag(kh, 16 * t + j, kk), b3_frag(kl, 16 * t + j, kk), qh, ql, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = (n0 + 16 * t + 4 * kk + r < M) ? s[t][r] * c2 : -INFINITY;
+            mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float alpha = fast_exp2(m - mx);
+        m = mx;
+        l *= alpha;
+        acc[0] *= alpha; acc[1] *= alpha;
+        uint32_t w[4];
+        if (dr.thr) b3_words_q(dr, q, n0, kk, lane, w);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[t][r] = fast_exp2(s[t][r] - mx); l += s[t][r]; }
+            if (dr.thr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] *= sa_keep(dr, w[t], r);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 ph, pl;
+            b3_split8(s[2 * g], s[2 * g + 1], ph, pl);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                acc[ct] = mma3(b3_frag(vh, 32 * g + 16 * ct + j, kk), b3_frag(vl, 32 * g + 16 * ct + j, kk), ph, pl, acc[ct]);
+        }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (q < M) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            *reinterpret_cast<float4*>(o + (size_t)q * d + h * 32 + 16 * c + 4 * kk) =
+                make_float4(acc[c][0] * inv, acc[c][1] * inv, acc[c][2] * inv, acc[c][3] * inv);
+        if (kk == 0) lse2[q] = m + __builtin_amdgcn_logf(l);
+    }
+}
+
+// dQ (+ delta): Q, dO row form (the wave's own rows); K, V row form and K T form streamed
+__global__ __launch_bounds__(64 * kSaWaves)
+void bag_sa_b3_dq_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* __restrict__ o, const float* __restrict__ d_o,
+                         const float* __restrict__ lse2, float* __restrict__ dqkv, float* __restrict__ delta, int M, int Mp, int d,
+                         float scale, float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch) {
+    __shared__ __attribute__((aligned(16))) __bf16 sm[6 * kB3Tile];
+    __bf16 *kh = sm, *kl = sm + kB3Tile, *vh = sm + 2 * kB3Tile, *vl = sm + 3 * kB3Tile, *kth = sm + 4 * kB3Tile, *ktl = sm + 5 * kB3Tile;
+    const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
+    const size_t head = (size_t)seq * H + h, hoff = head * Mp * 32;
+    dqkv += (size_t)seq * M * 3 * d;
+    o += (size_t)seq * M * d;
+    d_o += (size_t)seq * M * d;
+    lse2 += head * M;
+    delta += head * M;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    const int q = blockIdx.x * 64 + 16 * wv + j;
+    const SaDrop dr = sa_drop(drop_p, seed, offset, epoch, (int)head);
+    const bf16x8 qh = *reinterpret_cast<const bf16x8*>(Q.rh + hoff + (size_t)q * 32 + 8 * kk);
+    const bf16x8 ql = *reinterpret_cast<const bf16x8*>(Q.rl + hoff + (size_t)q * 32 + 8 * kk);
+    const bf16x8 doh = *reinterpret_cast<const bf16x8*>(DO.rh + hoff + (size_t)q * 32 + 8 * kk);
+    const bf16x8 dol = *reinterpret_cast<const bf16x8*>(DO.rl + hoff + (size_t)q * 32 + 8 * kk);
+    float dl = 0.f;
+    if (q < M) {
+        const float* op = o + (size_t)q * d + h * 32 + 8 * kk;
+        const float* gp = d_o + (size_t)q * d + h * 32 + 8 * kk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += op[e] * gp[e];
+    }
+    dl += __shfl_xor(dl, 16);
+    dl += __shfl_xor(dl, 32);
+    const float ls = q < M ? lse2[q] : INFINITY;
+    if (q < M && kk == 0) delta[q] = dl;
+    const float c2 = scale * kLog2e;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int n0 = 0; n0 < M; n0 += 64) {
+        __syncthreads();
+        b3_load(kh, K.rh + hoff + (size_t)n0 * 32);
+        b3_load(kl, K.rl + hoff + (size_t)n0 * 32);
+        b3_load(vh, V.rh + hoff + (size_t)n0 * 32);
+        b3_load(vl, V.rl + hoff + (size_t)n0 * 32);
+        b3_load(kth, K.th + hoff + (size_t)n0 * 32);
+        b3_load(ktl, K.tl + hoff + (size_t)n0 * 32);
+        __syncthreads();
+        uint32_t w[4];
+        if (dr.thr) b3_words_q(dr, q, n0, kk, lane, w);
+        f32x4 ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 s = mma3(b3_frag(kh, 16 * t + j, kk), b3_frag(kl, 16 * t + j, kk), qh, ql, f32x4{0.f, 0.f, 0.f, 0.f});
+            f32x4 dp = mma3(b3_frag(vh, 16 * t + j, kk), b3_frag(vl, 16 * t + j, kk), doh, dol, f32x4{0.f, 0.f, 0.f, 0.f});
+            if (dr.thr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[r] *= sa_keep(dr, w[t], r);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (n0 + 16 * t + 4 * kk + r < M) ? fast_exp2(s[r] * c2 - ls) : 0.f;
+                ds[t][r] = p * (dp[r] - dl);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 dh, dlo;
+            b3_split8(ds[2 * g], ds[2 * g + 1], dh, dlo);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                acc[ct] = mma3(b3_frag(kth, 32 * g + 16 * ct + j, kk), b3_frag(ktl, 32 * g + 16 * ct + j, kk), dh, dlo, acc[ct]);
+        }
+    }
+    if (q < M) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            *reinterpret_cast<float4*>(dqkv + (size_t)q * 3 * d + h * 32 + 16 * c + 4 * kk) =
+                make_float4(acc[c][0] * scale, acc[c][1] * scale, acc[c][2] * scale, acc[c][3] * scale);
+    }
+}
+
+// dK, dV: K, V row form (the wave's own rows); Q, dO row and T forms streamed
+__global__ __launch_bounds__(64 * kSaWaves)
+void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* __restrict__ lse2, const float* __restrict__ delta,
+                          float* __restrict__ dqkv, int M, int Mp, int d, float scale, float drop_p, unsigned long long seed,
+                          unsigned long long offset, const unsigned long long* epoch) {
+    __shared__ __attribute__((aligned(16))) __bf16 sm[8 * kB3Tile];
+    __shared__ __attribute__((aligned(16))) float st[128];
+    __bf16 *qh = sm, *ql = sm + kB3Tile, *gh = sm + 2 * kB3Tile, *gl = sm + 3 * kB3Tile;
+    __bf16 *qth = sm + 4 * kB3Tile, *qtl = sm + 5 * kB3Tile, *gth = sm + 6 * kB3Tile, *gtl = sm + 7 * kB3Tile;
+    float *ls_t = st, *dl_t = st + 64;
+    const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
+    const size_t head = (size_t)seq * H + h, hoff = head * Mp * 32;
+    dqkv += (size_t)seq * M * 3 * d;
+    lse2 += head * M;
+    delta += head * M;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    const int key = blockIdx.x * 64 + 16 * wv + j;
+    const SaDrop dr = sa_drop(drop_p, seed, offset, epoch, (int)head);
+    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(K.rh + hoff + (size_t)key * 32 + 8 * kk);
+    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(K.rl + hoff + (size_t)key * 32 + 8 * kk);
+    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(V.rh + hoff + (size_t)key * 32 + 8 * kk);
+    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(V.rl + hoff + (size_t)key * 32 + 8 * kk);
+    const float c2 = scale * kLog2e;
+    f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int q0 = 0; q0 < M; q0 += 64) {
+        __syncthreads();
+        b3_load(qh, Q.rh + hoff + (size_t)q0 * 32);
+        b3_load(ql, Q.rl + hoff + (size_t)q0 * 32);
+        b3_load(gh, DO.rh + hoff + (size_t)q0 * 32);
+        b3_load(gl, DO.rl + hoff + (size_t)q0 * 32);
+        b3_load(qth, Q.th + hoff + (size_t)q0 * 32);
+        b3_load(qtl, Q.tl + hoff + (size_t)q0 * 32);
+        b3_load(gth, DO.th + hoff + (size_t)q0 * 32);
+        b3_load(gtl, DO.tl + hoff + (size_t)q0 * 32);
+        if (threadIdx.x < 64) {
+            const int qq = q0 + threadIdx.x;
+            ls_t[threadIdx.x] = qq < M ? lse2[qq] : INFINITY;
+            dl_t[threadIdx.x] = qq < M ? delta[qq] : 0.f;
+        }
+        __syncthreads();
+        uint32_t w[4][4];
+        if (dr.thr) b3_blocks_key(dr, key, q0, kk, lane, w);
+        f32x4 pd[4], ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 s = mma3(b3_frag(qh, 16 * t + j, kk), b3_frag(ql, 16 * t + j, kk), kh, kl, f32x4{0.f, 0.f, 0.f, 0.f});
+            f32x4 dp = mma3(b3_frag(gh, 16 * t + j, kk), b3_frag(gl, 16 * t + j, kk), vh, vl, f32x4{0.f, 0.f, 0.f, 0.f});
+            const float4 ls = *reinterpret_cast<const float4*>(ls_t + 16 * t + 4 * kk);
+            const float4 dl = *reinterpret_cast<const float4*>(dl_t + 16 * t + 4 * kk);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = fast_exp2(s[r] * c2 - lsv[r]);
+                const float keep = dr.thr ? sa_keep(dr, w[t][r], key & 3) : 1.0f;
+                pd[t][r] = p * keep;
+                ds[t][r] = p * (dp[r] * keep - dlv[r]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 ph, pl, sh_, sl_;
+            b3_split8(pd[2 * g], pd[2 * g + 1], ph, pl);
+            b3_split8(ds[2 * g], ds[2 * g + 1], sh_, sl_);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                dv[ct] = mma3(b3_frag(gth, 32 * g + 16 * ct + j, kk), b3_frag(gtl, 32 * g + 16 * ct + j, kk), ph, pl, dv[ct]);
+                dk[ct] = mma3(b3_frag(qth, 32 * g + 16 * ct + j, kk), b3_frag(qtl, 32 * g + 16 * ct + j, kk), sh_, sl_, dk[ct]);
+            }
+        }
+    }
+    if (key < M) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float* at = dqkv + (size_t)key * 3 * d + h * 32 + 16 * c + 4 * kk;
+            *reinterpret_cast<float4*>(at + d) = make_float4(dk[c][0] * scale, dk[c][1] * scale, dk[c][2] * scale, dk[c][3] * scale);
+            *reinterpret_cast<float4*>(at + 2 * d) = make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]);
+        }
+    }
+}
+
+inline int b3_mp(int M) { return (M + 63) / 64 * 64; }
+inline bool b3_applies(int d, int H) { return g_sa_b3 && H > 1 && d == 32 * H; }
+// one operand's forms inside a workspace of bf16: [rh | rl | th | tl], each n_seq * H * Mp * 32 elements
+inline B3Form b3_form(__bf16* base, int idx, size_t each) {
+    __bf16* p = base + (size_t)idx * 4 * each;
+    return B3Form{p, p + each, p + 2 * each, p + 3 * each};
+}
+inline int b3_split(const float* src, int ld, int col0, int n_seq, int M, int H, const B3Form& f, bool rows, bool tform, hipStream_t s) {
+    const int Mp = b3_mp(M);
+    sa_b3_split_kernel<<<dim3(Mp / 32, H, n_seq), 256, 0, s>>>(src, ld, col0, M, Mp, rows ? const_cast<__bf16*>(f.rh) : nullptr,
+                                                             rows ? const_cast<__bf16*>(f.rl) : nullptr,
+                                                             tform ? const_cast<__bf16*>(f.th) : nullptr,
+                                                             tform ? const_cast<__bf16*>(f.tl) : nullptr);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
 inline bool sa_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
 int mpo_bag_sa_supported_head_dim(int hd) { return hd == 16 || hd == 32 || hd == 64 || hd == 128 || hd == 256; }
+int mpo_bag_sa_set_bf16x3(int enabled) {
+    const int was = g_sa_b3 ? 1 : 0;
+    g_sa_b3 = enabled != 0;
+    return was;
+}
+// floats of saved state: the log-sum-exps (rounded up to 16 bytes) + on the three-term bf16 path the forward's operand forms
+// (Q rows, K rows + T, V rows + T: 3 operands x 4 arrays of bf16), which the backward reads again
+size_t mpo_bag_sa_saved_floats(int n_seq, int M, int d, int H) {
+    size_t n = ((size_t)n_seq * H * M + 3) / 4 * 4;
+    if (H > 1 && d == 32 * H) n += 3 * 4 * ((size_t)n_seq * H * b3_mp(M) * 32) / 2;
+    return n;
+}
+// floats of backward scratch: delta + (three-term path) the four forms of dO
+size_t mpo_bag_sa_bwd_floats(int n_seq, int M, int d, int H) {
+    size_t n = ((size_t)n_seq * H * M + 3) / 4 * 4;
+    if (H > 1 && d == 32 * H) n += 4 * ((size_t)n_seq * H * b3_mp(M) * 32) / 2;
+    return n;
+}
 
 int mpo_launch_bag_sa_fwd(const float* qkv, int n_seq, int M, int d, int H, float drop_p, unsigned long long seed,
-                          unsigned long long offset, const unsigned long long* epoch, float* o, float* lse2, float* map, hipStream_t s) {
+                          unsigned long long offset, const unsigned long long* epoch, float* o, float* saved, float* map, hipStream_t s) {
     MPO_CHECK(n_seq >= 1 && M >= 1 && H >= 1 && d % H == 0, "bag self-attention: %d sequences of %d rows, d=%d, heads=%d", n_seq, M, d, H);
     MPO_CHECK(n_seq <= 65535 && H <= 65535, "bag self-attention: %d sequences x %d heads exceed the grid", n_seq, H);
     const int hd = d / H;
     MPO_CHECK(mpo_bag_sa_supported_head_dim(hd), "bag self-attention: head dimension %d (16, 32, 64, 128 or 256)", hd);
     MPO_CHECK(map == nullptr || H == 1, "bag self-attention: the M x M map is returned for one head only (heads=%d)", H);
-    MPO_CHECK(sa_al16(qkv) && sa_al16(o) && (map == nullptr || sa_al16(map)), "bag self-attention: buffers must be 16-byte aligned");
+    MPO_CHECK(sa_al16(qkv) && sa_al16(o) && sa_al16(saved) && (map == nullptr || sa_al16(map)), "bag self-attention: buffers must be 16-byte aligned");
+    float* lse2 = saved;
+    if (b3_applies(d, H)) {
+        const int Mp = b3_mp(M);
+        const size_t each = (size_t)n_seq * H * Mp * 32;
+        __bf16* forms = reinterpret_cast<__bf16*>(saved + ((size_t)n_seq * H * M + 3) / 4 * 4);
+        const B3Form Q = b3_form(forms, 0, each), K = b3_form(forms, 1, each), V = b3_form(forms, 2, each);
+        if (int rc = b3_split(qkv, 3 * d, 0, n_seq, M, H, Q, true, true, s)) return rc;
+        if (int rc = b3_split(qkv, 3 * d, d, n_seq, M, H, K, true, true, s)) return rc;
+        if (int rc = b3_split(qkv, 3 * d, 2 * d, n_seq, M, H, V, true, true, s)) return rc;
+        bag_sa_b3_fwd_kernel<<<dim3(Mp / 64, H, n_seq), 64 * kSaWaves, 0, s>>>(Q, K, V, o, lse2, M, Mp, d, 1.0f / sqrtf(32.0f), drop_p, seed,
+                                                                              offset, epoch);
+        MPO_LAUNCH_CHECK();
+        return 0;
+    }
     switch (hd) {
         case 16: return sa_forward<16>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
         case 32: return sa_forward<32>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
@@ -420,14 +800,33 @@ int mpo_launch_bag_sa_fwd(const float* qkv, int n_seq, int M, int d, int H, floa
         default: return sa_forward<256>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
     }
 }
-int mpo_launch_bag_sa_bwd(const float* qkv, const float* o, const float* lse2, const float* d_o, int n_seq, int M, int d, int H,
+// scratch: mpo_bag_sa_bwd_floats() floats
+int mpo_launch_bag_sa_bwd(const float* qkv, const float* o, const float* saved, const float* d_o, int n_seq, int M, int d, int H,
                           float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
-                          float* dqkv, float* delta, hipStream_t s) {
+                          float* dqkv, float* scratch, hipStream_t s) {
     MPO_CHECK(n_seq >= 1 && M >= 1 && H >= 1 && d % H == 0, "bag self-attention: %d sequences of %d rows, d=%d, heads=%d", n_seq, M, d, H);
     MPO_CHECK(n_seq <= 65535 && H <= 65535, "bag self-attention: %d sequences x %d heads exceed the grid", n_seq, H);
     const int hd = d / H;
     MPO_CHECK(mpo_bag_sa_supported_head_dim(hd), "bag self-attention: head dimension %d (16, 32, 64, 128 or 256)", hd);
-    MPO_CHECK(sa_al16(qkv) && sa_al16(o) && sa_al16(d_o) && sa_al16(dqkv), "bag self-attention: buffers must be 16-byte aligned");
+    MPO_CHECK(sa_al16(qkv) && sa_al16(o) && sa_al16(d_o) && sa_al16(dqkv) && sa_al16(saved) && sa_al16(scratch),
+              "bag self-attention: buffers must be 16-byte aligned");
+    const float* lse2 = saved;
+    float* delta = scratch;
+    if (b3_applies(d, H)) {
+        const int Mp = b3_mp(M);
+        const size_t each = (size_t)n_seq * H * Mp * 32, lse_floats = ((size_t)n_seq * H * M + 3) / 4 * 4;
+        __bf16* forms = reinterpret_cast<__bf16*>(const_cast<float*>(saved) + lse_floats);
+        const B3Form Q = b3_form(forms, 0, each), K = b3_form(forms, 1, each), V = b3_form(forms, 2, each);
+        const B3Form DO = b3_form(reinterpret_cast<__bf16*>(scratch + lse_floats), 0, each);
+        if (int rc = b3_split(d_o, d, 0, n_seq, M, H, DO, true, true, s)) return rc;
+        const float scale = 1.0f / sqrtf(32.0f);
+        const dim3 grid(Mp / 64, H, n_seq);
+        bag_sa_b3_dq_kernel<<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, o, d_o, lse2, dqkv, delta, M, Mp, d, scale, drop_p, seed, offset, epoch);
+        MPO_LAUNCH_CHECK();
+        bag_sa_b3_dkv_kernel<<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, lse2, delta, dqkv, M, Mp, d, scale, drop_p, seed, offset, epoch);
+        MPO_LAUNCH_CHECK();
+        return 0;
+    }
     switch (hd) {
         case 16: return sa_backward<16>(qkv, o, lse2, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, delta, s);
         case 32: return sa_backward<32>(qkv, o, lse2, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, delta, s);

@@ -225,14 +225,18 @@ int mpo_launch_ln_bwd_params_only(const float* dy, const float* x, const float* 
                                   hipStream_t s);
 // longest token axis the LDS-resident attention kernels of tail.hip take; longer axes (the rows of a bag) run bag_selfattn.hip
 constexpr int kSmallAttnMaxT = 16;
-// self-attention over the M rows of a bag (bag_selfattn.hip): qkv [n_seq][M][3 d] -> o [n_seq][M][d], lse2 [n_seq][H][M];
-// map (optional, H == 1) [n_seq][M][M]; backward: dqkv [n_seq][M][3 d], delta [n_seq][H][M] scratch
+// self-attention over the M rows of a bag (bag_selfattn.hip): qkv [n_seq][M][3 d] -> o [n_seq][M][d]; saved:
+// mpo_bag_sa_saved_floats() floats (log-sum-exps + the three-term bf16 path's operand forms); map (optional, H == 1)
+// [n_seq][M][M]; backward: dqkv [n_seq][M][3 d], scratch of mpo_bag_sa_bwd_floats() floats
 int mpo_bag_sa_supported_head_dim(int hd);
+int mpo_bag_sa_set_bf16x3(int enabled);
+size_t mpo_bag_sa_saved_floats(int n_seq, int M, int d, int H);
+size_t mpo_bag_sa_bwd_floats(int n_seq, int M, int d, int H);
 int mpo_launch_bag_sa_fwd(const float* qkv, int n_seq, int M, int d, int H, float drop_p, unsigned long long seed,
-                          unsigned long long offset, const unsigned long long* epoch, float* o, float* lse2, float* map, hipStream_t s);
-int mpo_launch_bag_sa_bwd(const float* qkv, const float* o, const float* lse2, const float* d_o, int n_seq, int M, int d, int H,
+                          unsigned long long offset, const unsigned long long* epoch, float* o, float* saved, float* map, hipStream_t s);
+int mpo_launch_bag_sa_bwd(const float* qkv, const float* o, const float* saved, const float* d_o, int n_seq, int M, int d, int H,
                           float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
-                          float* dqkv, float* delta, hipStream_t s);
+                          float* dqkv, float* scratch, hipStream_t s);
 int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, int T, int d, int H, float drop_p,
                              unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
                              hipStream_t s);

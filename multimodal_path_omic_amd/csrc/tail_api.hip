@@ -71,8 +71,8 @@ void enc_carve(C& c, EncLayerSaved* out, int B, int T, int d, int ff, int H) {
     EncLayerSaved s;
     s.qkv = c.take(R * 3 * d);
     // attention state: the two T x T probability matrices per head of the token tail, or (T = the rows of a bag) one
-    // log-sum-exp per head and row
-    s.psave = c.take(T <= kSmallAttnMaxT ? (size_t)B * 2 * H * T * T : (size_t)B * H * T);
+    // log-sum-exp per head and row (+ the operand forms of the three-term bf16 path)
+    s.psave = c.take(T <= kSmallAttnMaxT ? (size_t)B * 2 * H * T * T : mpo_bag_sa_saved_floats(B, T, d, H));
     s.o = c.take(R * d);
     s.s1 = c.take(R * d); s.st1 = c.take(2 * R); s.x1 = c.take(R * d); s.f = c.take(R * ff);
     s.s2 = c.take(R * d); s.st2 = c.take(2 * R); s.x2 = c.take(R * d);
@@ -98,6 +98,9 @@ size_t mpo_encoder_workspace_bytes(int n_slides, int T, int d, int ff) {
     Sizer s;
     for (int l = 0; l < 8; ++l) {                          // one buffer set per layer (max 8 layers)
         s.floats(R * d); s.floats(R * ff); s.floats(R * d); s.floats(R * d); s.floats(R * d); s.floats(R * 3 * d); s.floats(R * d);
+        // long token axes: scratch of the bag self-attention backward (heads are not known here: 8 of width 32 is the
+        // one geometry with more than the per-head row sums, and d floats per row covers it)
+        if (T > kSmallAttnMaxT) s.floats(mpo_bag_sa_bwd_floats(n_slides, T, d, d / 32 > 0 ? d / 32 : 1) + (size_t)R * d);
     }
     return s.off + 256;
 }
@@ -248,10 +251,10 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
         if (T <= kSmallAttnMaxT) {
             RC(mpo_launch_mha_small_bwd(S[l].qkv, S[l].psave, dob, dqkv, BT, T, d, heads, stream));
         } else {
-            // df (RT x ff floats, consumed above) holds the per-head row sums delta [BT][heads][T]
-            MPO_CHECK(heads <= ff, "encoder backward: %d heads need a delta buffer larger than the feed-forward one (%d)", heads, ff);
+            float* sa_ws = ws.floats(mpo_bag_sa_bwd_floats(BT, T, d, heads));
+            MPO_CHECK(sa_ws, "encoder backward: workspace too small for the attention scratch (%zu bytes)", workspace_bytes);
             const DropSpec d0 = stream_of(drop_p, seed, base, stride, 0, rng_epoch);
-            RC(mpo_launch_bag_sa_bwd(S[l].qkv, S[l].o, S[l].psave, dob, BT, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, dqkv, df, stream));
+            RC(mpo_launch_bag_sa_bwd(S[l].qkv, S[l].o, S[l].psave, dob, BT, T, d, heads, d0.p, d0.seed, d0.off, d0.epoch, dqkv, sa_ws, stream));
         }
         // qkv = in W_in^T + b_in;  d_in = ds1 + dqkv W_in
         RC(pairs([&](int br) {
@@ -269,7 +272,9 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
 // ------------------------------------------------------------------------------------------- f3 bag self-attention
 // The attention core of nn.MultiheadAttention over the M rows of a bag (models/ge_nacagat/ge_nacagat.py:27,49): the packed
 // projections qkv [n_bags][M][3 d] come from the caller's in_proj product, the out_proj follows on the caller's side.
-size_t mpo_bag_self_attention_saved_floats(int n_bags, int M, int heads) { return (size_t)n_bags * heads * M; }
+size_t mpo_bag_self_attention_saved_floats(int n_bags, int M, int d, int heads) { return mpo_bag_sa_saved_floats(n_bags, M, d, heads); }
+size_t mpo_bag_self_attention_workspace_bytes(int n_bags, int M, int d, int heads) { return mpo_bag_sa_bwd_floats(n_bags, M, d, heads) * sizeof(float); }
+int mpo_set_bag_self_attention_bf16x3(int enabled) { return mpo_bag_sa_set_bf16x3(enabled); }
 int mpo_bag_self_attention_forward(const float* qkv, int n_bags, int M, int d, int heads, float drop_p, uint64_t seed, uint64_t offset,
                                    const uint64_t* rng_epoch, float* out, float* saved, float* attn_map, mpo_stream_t stream) {
     MPO_CHECK(qkv && out && saved, "bag self-attention: NULL buffer");
@@ -280,7 +285,7 @@ int mpo_bag_self_attention_backward(const float* qkv, const float* out, const fl
                                     int heads, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch, float* d_qkv,
                                     void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     MPO_CHECK(qkv && out && saved && d_out && d_qkv, "bag self-attention backward: NULL buffer");
-    MPO_CHECK(workspace && workspace_bytes >= mpo_bag_self_attention_saved_floats(n_bags, M, heads) * sizeof(float),
+    MPO_CHECK(workspace && workspace_bytes >= mpo_bag_self_attention_workspace_bytes(n_bags, M, d, heads),
               "bag self-attention backward: workspace too small (%zu bytes)", workspace_bytes);
     return mpo_launch_bag_sa_bwd(qkv, out, saved, d_out, n_bags, M, d, heads, drop_p, seed, offset, (const unsigned long long*)rng_epoch,
                                  d_qkv, static_cast<float*>(workspace), (hipStream_t)stream);

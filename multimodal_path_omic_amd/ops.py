@@ -696,7 +696,7 @@ class BagSelfAttentionFn(torch.autograd.Function):
         d = d3 // 3
         qkv = qkv.contiguous()
         out = torch.empty((n_bags, m, d), device=qkv.device, dtype=torch.float32)
-        saved = torch.empty(lib.mpo_bag_self_attention_saved_floats(n_bags, m, heads), device=qkv.device, dtype=torch.float32)
+        saved = torch.empty(lib.mpo_bag_self_attention_saved_floats(n_bags, m, d, heads), device=qkv.device, dtype=torch.float32)
         amap = torch.empty((n_bags, m, m), device=qkv.device, dtype=torch.float32) if need_map else None
         seed, off = _reserve(1) if drop_p > 0 else (0, 0)
         L.check(lib.mpo_bag_self_attention_forward(L.ptr(qkv), n_bags, m, d, heads, float(drop_p), seed, off, _epoch(), L.ptr(out),
@@ -714,7 +714,7 @@ class BagSelfAttentionFn(torch.autograd.Function):
         n_bags, m, d, heads = ctx.geom
         drop_p, seed, off = ctx.drop
         d_qkv = torch.empty_like(qkv)
-        ws = _workspace(saved.numel() * 4, qkv.device)
+        ws = _workspace(lib.mpo_bag_self_attention_workspace_bytes(n_bags, m, d, heads), qkv.device)
         d_out = d_out.contiguous()
         L.check(lib.mpo_bag_self_attention_backward(L.ptr(qkv), L.ptr(out), L.ptr(saved), L.ptr(d_out), n_bags, m, d, heads, drop_p,
                                                     seed, off, _epoch(), L.ptr(d_qkv), L.ptr(ws), ws.numel(), L.stream_of(qkv)),

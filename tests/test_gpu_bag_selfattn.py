@@ -45,23 +45,44 @@ CASES = [  # n_bags, M, d, heads, q gain
     (1, 200, 512, 8, 1.0), (1, 257, 256, 1, 6.0), (1, 515, 256, 8, 6.0), (1, 1, 256, 8, 1.0), (1, 17, 256, 1, 1.0)]
 
 
+def _b3_modes(d, heads):
+    """Several heads of width 32 run on three-term bf16 MFMAs by default (~16 mantissa bits per operand); the verification hook
+    keeps them on the fp32 kernels.  -> [(hook value, output bar, gradient bar)]"""
+    return [(1, 1e-4, 1e-3), (0, 1e-5, 1e-4)] if heads > 1 and d == 32 * heads else [(1, 1e-5, 1e-4)]
+
+
+class bf16x3:
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        from multimodal_path_omic_amd import _lib as L
+        self.was = L.lib().mpo_set_bag_self_attention_bf16x3(self.on)
+
+    def __exit__(self, *exc):
+        from multimodal_path_omic_amd import _lib as L
+        L.lib().mpo_set_bag_self_attention_bf16x3(self.was)
+
+
 @pytest.mark.parametrize("n,m,d,heads,gain", CASES)
 def test_attention_core_equals_torch(dev, n, m, d, heads, gain):
     g = syn.rng(7000 + m + heads)
     qkv = syn.normal(g, (n, m, 3 * d))
     qkv[..., :d] *= gain                                       # gain 6: peaky rows (a few keys take all the mass)
     probe = syn.normal(g, (n, m, d))
-    x = qkv.to(dev).requires_grad_(True)
-    out, amap = ops.BagSelfAttentionFn.apply(x, heads, 0.0, heads == 1)
-    (out * probe.to(dev)).sum().backward()
     xr = qkv.double().requires_grad_(True)
     out_r, p_r = attention_ref(xr, heads)
     (out_r * probe.double()).sum().backward()
-    assert relmax(out, out_r) < 1e-5
-    assert relmax(x.grad, xr.grad) < 1e-4, relmax(x.grad, xr.grad)
-    for part in range(3):                                      # dq, dk, dv separately: none hides behind a larger one
-        sl = slice(part * d, (part + 1) * d)
-        assert relmax(x.grad[..., sl], xr.grad[..., sl], part_scale(xr.grad)(sl)) < 1e-4, part
+    for hook, out_bar, grad_bar in _b3_modes(d, heads):
+        with bf16x3(hook):
+            x = qkv.to(dev).requires_grad_(True)
+            out, amap = ops.BagSelfAttentionFn.apply(x, heads, 0.0, heads == 1)
+            (out * probe.to(dev)).sum().backward()
+        assert relmax(out, out_r) < out_bar, (hook, relmax(out, out_r))
+        assert relmax(x.grad, xr.grad) < grad_bar, (hook, relmax(x.grad, xr.grad))
+        for part in range(3):                                  # dq, dk, dv separately: none hides behind a larger one
+            sl = slice(part * d, (part + 1) * d)
+            assert relmax(x.grad[..., sl], xr.grad[..., sl], part_scale(xr.grad)(sl)) < grad_bar, (hook, part)
     if heads == 1:
         assert amap.shape == (n, m, m)
         ref = p_r[:, 0].detach()
@@ -97,6 +118,12 @@ def test_attention_dropout_mask_is_shared_by_forward_and_backward(dev, m, d, hea
     """Dropout on the probabilities: the mask is never stored.  It is read back here through identity-block values, must be
     {0, 1/(1-p)} at the stated rate, and a torch restatement using exactly that mask must reproduce the forward and all
     three gradients -- i.e. forward, dQ and dK/dV kernels regenerate the same mask."""
+    for hook, out_bar, grad_bar in _b3_modes(d, heads):
+        with bf16x3(hook):
+            _dropout_mask_check(dev, m, d, heads, out_bar, grad_bar)
+
+
+def _dropout_mask_check(dev, m, d, heads, out_bar, grad_bar):
     g = syn.rng(7100 + m)
     qkv = syn.normal(g, (1, m, 3 * d)) * 0.5
     probe = syn.normal(g, (1, m, d))
@@ -115,10 +142,10 @@ def test_attention_dropout_mask_is_shared_by_forward_and_backward(dev, m, d, hea
     xr = qkv.double().requires_grad_(True)
     out_r, _ = attention_ref(xr, heads, keep=(keep > 0.5).double() / (1 - p))
     (out_r * probe.double()).sum().backward()
-    assert relmax(out, out_r) < 1e-5
+    assert relmax(out, out_r) < out_bar
     for part in range(3):
         sl = slice(part * d, (part + 1) * d)
-        assert relmax(x.grad[..., sl], xr.grad[..., sl], part_scale(xr.grad)(sl)) < 1e-4, part
+        assert relmax(x.grad[..., sl], xr.grad[..., sl], part_scale(xr.grad)(sl)) < grad_bar, part
     # another offset = another mask
     ops._rng_calls = offset + 1
     out2, _ = ops.BagSelfAttentionFn.apply(qkv.to(dev), heads, p, False)
