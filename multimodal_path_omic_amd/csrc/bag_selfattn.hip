@@ -16,10 +16,10 @@
 // The row-major K / V (or Q / dO) tile in LDS serves both as the A operand of the score product (one ds_read_b128 per four
 // MFMAs, row stride HD + 4 floats: conflict-free) and, read one float per MFMA, as the transposed A operand of the second.
 //
-// Dropout on the probabilities (the encoder layers' attention dropout, p = 0.25 in training): one Philox call per 4 x 4
-// block of (query, key), 8 bits per element (realised p = round(256 p) / 256, as in the fused patch layer); forward, dQ and
-// dK/dV regenerate the same block from (seed, stream, head, q / 4, key / 4) -- both orientations hold four elements of one
-// block per lane, so each pays one call per four elements.
+// Dropout on the probabilities (the encoder layers' attention dropout, p = 0.25 in training): one counter-hash call per
+// 4 x 4 block of (query, key), 8 bits per element (realised p = round(256 p) / 256, as in the fused patch layer); forward, dQ
+// and dK/dV regenerate the same block from (seed, stream, head, q / 4, key / 4) -- both orientations hold four elements of
+// one block per lane.
 #include "mpo_common.h"
 #include "mpo_kernels.h"
 
@@ -35,10 +35,17 @@ template <int HD> struct SaCfg {
     static constexpr size_t TILE_FLOATS = (size_t)BN * LDR;
 };
 
+// Counter-based hash, not Philox: 32-bit integer multiplies run at a quarter of the vector rate on this chip, and the ten
+// Philox rounds (40 multiplies) of one block cost a third of the bf16 kernels' step.  One block = 16 bytes = four words, each
+// the murmur3 finaliser (two multiplies, full avalanche) of a key mixed with the block's coordinates.
+__device__ __forceinline__ uint32_t sa_fmix(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
 struct SaDrop {
     unsigned thr;                                            // keep when byte >= thr (0: no dropout)
     float inv_keep;
-    uint32_t k0, k1, c2, c3;
+    uint32_t key;                                            // seed, stream offset (+ epoch) and head, hashed
 };
 __device__ __forceinline__ SaDrop sa_drop(float p, unsigned long long seed, unsigned long long offset,
                                           const unsigned long long* epoch, int head) {
@@ -47,13 +54,18 @@ __device__ __forceinline__ SaDrop sa_drop(float p, unsigned long long seed, unsi
     d.thr = t > 255u ? 255u : t;
     d.inv_keep = 256.0f / (256.0f - (float)d.thr);
     const unsigned long long ctr = epoch_offset(offset, epoch);
-    d.k0 = (uint32_t)seed; d.k1 = (uint32_t)(seed >> 32);
-    d.c2 = (uint32_t)ctr ^ ((uint32_t)head * 0x9E3779B1u);
-    d.c3 = (uint32_t)(ctr >> 32) | 0x80000000u;              // the element-counter streams of the other kernels have c3 = 0
+    uint32_t k = sa_fmix((uint32_t)seed ^ 0x5A17u);
+    k = sa_fmix(k ^ (uint32_t)(seed >> 32));
+    k = sa_fmix(k ^ (uint32_t)ctr);
+    k = sa_fmix(k ^ (uint32_t)(ctr >> 32));
+    d.key = sa_fmix(k ^ (uint32_t)head);
     return d;
 }
 // the 16 bytes of block (q / 4, key / 4); element (q % 4, key % 4) is byte 4 * (q % 4) + key % 4
-__device__ __forceinline__ uint4 sa_block(const SaDrop& d, int qb, int kb) { return philox4x32((uint32_t)kb, (uint32_t)qb, d.c2, d.c3, d.k0, d.k1); }
+__device__ __forceinline__ uint4 sa_block(const SaDrop& d, int qb, int kb) {
+    const uint32_t x = (d.key ^ ((uint32_t)qb * 0x9E3779B1u)) + (uint32_t)kb * 0x85EBCA77u;
+    return make_uint4(sa_fmix(x), sa_fmix(x + 0x27D4EB2Fu), sa_fmix(x + 0x4FA9D65Eu), sa_fmix(x + 0x777EC18Du));
+}
 __device__ __forceinline__ float sa_keep(const SaDrop& d, uint32_t word, int byte) {
     return ((word >> (8 * byte)) & 255u) >= d.thr ? d.inv_keep : 0.f;
 }
@@ -399,18 +411,29 @@ int sa_backward(const float* qkv, const float* o, const float* lse2, const float
     return 0;
 }
 // ================================================================================================ three-term bf16 path
-// Head dimension 32 with several heads (the encoder layers: no map is returned, so the bar is the model output's, not the
-// map's): every operand is split x = hi + lo into two bf16 and each product runs as hi*hi + lo*hi + hi*lo on
-// v_mfma_f32_16x16x32_bf16 -- one instruction covers the whole head dimension (scores) or 32 keys (second products), three
-// of them cost 48 cycles against 256 for the eight fp32 instructions of the same tile.  ~16 mantissa bits per operand.
-// A split pass writes each operand once in the two forms the kernels read, so every tile load is a contiguous 4-KiB copy:
-//   row form  R[head][Mp][32]               (A operand of a score product, or a wave's own rows as B operand)
-//   T form    T[head][Mp / 32][32 c][32 p]  (A operand of a second product: for column c the 32 rows of a group in MFMA
+// Every operand is split x = hi + lo into two bf16 and each product runs as hi*hi + lo*hi + hi*lo on
+// v_mfma_f32_16x16x32_bf16: three instructions (48 cycles) cover 32 of the inner dimension, against eight fp32 instructions
+// (256 cycles).  ~16 mantissa bits per operand -- the arithmetic the fused patch layer's co-attention uses for its query
+// operand, inside the 1e-3 bar on maps (checked on peaky rows).  Used for head dimensions 32 (the encoder layers) and 256
+// (the one-head layer whose map is returned); the fp32 kernels above serve the other widths and remain selectable
+// (mpo_set_bag_self_attention_bf16x3) as the check of this path.
+// A split pass writes each operand once in the two forms the kernels read, so every tile load is a contiguous copy:
+//   row form  R[head][Mp][HD]               (A operand of a score product, or a wave's own rows as B operand)
+//   T form    T[head][Mp / 32][HD c][32 p]  (A operand of a second product: for column c the 32 rows of a group in MFMA
 //             k-slot order p = 8 kk + 4 u + e  <->  row 16 u + 4 kk + e, i.e. the order in which a lane holds two
 //             consecutive score tiles' results)
 // Mp = M rounded up to 64, padding rows zero.  The same transposed-tile scheme as the fp32 kernels above otherwise.
-constexpr int kB3Ld = 40;                                  // bf16 per LDS row: 64 data bytes + 16 pad (conflict-free b128 reads)
-constexpr int kB3Tile = 64 * kB3Ld;                        // one 64-row (or 2 x 32-column) tile, in bf16 elements
+template <int HD> struct B3Cfg {
+    static constexpr int BN = HD == 32 ? 64 : 32;           // streamed rows per step
+    static constexpr int NT = BN / 16;                       // 16-row tiles per step
+    static constexpr int NG = BN / 32;                       // 32-row groups per step
+    static constexpr int KS = HD / 32;                       // MFMA k-steps of a score product
+    static constexpr int CT = HD / 16;                       // 16-column tiles of the head dimension
+    static constexpr int RLD = HD + 8;                       // LDS row stride of a row-form tile, bf16 (16 pad bytes)
+    static constexpr int TLD = 40;                           // LDS row stride of a T-form tile, bf16 (64 data + 16 pad bytes)
+    static constexpr int RTILE = BN * RLD;                   // bf16 elements of one row-form tile
+    static constexpr int TTILE = NG * HD * TLD;              // ... of one T-form tile
+};
 bool g_sa_b3 = true;
 
 struct B3Form { const __bf16 *rh, *rl, *th, *tl; };
@@ -421,13 +444,97 @@ __device__ __forceinline__ f32x4 mma3(const bf16x8& ah, const bf16x8& al, const 
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
     return acc;
 }
-// 4 KiB of a form (64 rows x 64 B, contiguous) -> LDS rows of 80 B
-__device__ __forceinline__ void b3_load(__bf16* tile, const __bf16* __restrict__ src) {
-    const uint4 v = reinterpret_cast<const uint4*>(src)[threadIdx.x];
-    *reinterpret_cast<uint4*>(tile + (threadIdx.x >> 2) * kB3Ld + (threadIdx.x & 3) * 8) = v;
+// Tiles travel global -> registers -> LDS in two steps so that the loads of step n + 1 are in flight while step n computes
+// (one workgroup per CU at head dimension 256: nothing else would hide them).
+// BN rows of a row form (contiguous in memory) <-> LDS rows of HD + 8 bf16
+// (At head dimension 256 the staged pieces -- 16 to 36 uint4 per thread -- no longer fit next to the operands and
+// accumulators: measured with the prefetch on, dK/dV 5.9 -> 8.6 ms at 15 000 rows through spills.  There the tiles are loaded
+// and committed in one go, kPipe = false.)
+template <int HD> struct B3Stage {
+    static constexpr bool kPipe = HD <= 64;
+    static constexpr int RV = kPipe ? B3Cfg<HD>::BN * (HD / 8) / (64 * kSaWaves) : 1;     // 16-byte pieces per thread of a row-form tile
+    static constexpr int TV = kPipe ? B3Cfg<HD>::NG * HD * 4 / (64 * kSaWaves) : 1;       // ... of a T-form tile (1: unused)
+};
+template <int HD>
+__device__ __forceinline__ void b3_stage_rows(uint4 (&v)[B3Stage<HD>::RV], const __bf16* __restrict__ src) {
+#pragma unroll
+    for (int i = 0; i < B3Stage<HD>::RV; ++i) v[i] = reinterpret_cast<const uint4*>(src)[threadIdx.x + 64 * kSaWaves * i];
 }
-__device__ __forceinline__ bf16x8 b3_frag(const __bf16* tile, int row, int kk) {
-    return *reinterpret_cast<const bf16x8*>(tile + row * kB3Ld + 8 * kk);
+template <int HD>
+__device__ __forceinline__ void b3_commit_rows(__bf16* tile, const uint4 (&v)[B3Stage<HD>::RV]) {
+    using C = B3Cfg<HD>;
+    constexpr int V8 = HD / 8;
+#pragma unroll
+    for (int i = 0; i < B3Stage<HD>::RV; ++i) {
+        const int idx = threadIdx.x + 64 * kSaWaves * i;
+        *reinterpret_cast<uint4*>(tile + (idx / V8) * C::RLD + (idx % V8) * 8) = v[i];
+    }
+}
+// NG groups of a T form (contiguous: [group][HD c][32 slots]) <-> LDS rows of 40 bf16
+template <int HD>
+__device__ __forceinline__ void b3_stage_t(uint4 (&v)[B3Stage<HD>::TV], const __bf16* __restrict__ src) {
+#pragma unroll
+    for (int i = 0; i < B3Stage<HD>::TV; ++i) v[i] = reinterpret_cast<const uint4*>(src)[threadIdx.x + 64 * kSaWaves * i];
+}
+template <int HD>
+__device__ __forceinline__ void b3_commit_t(__bf16* tile, const uint4 (&v)[B3Stage<HD>::TV]) {
+    using C = B3Cfg<HD>;
+#pragma unroll
+    for (int i = 0; i < B3Stage<HD>::TV; ++i) {
+        const int idx = threadIdx.x + 64 * kSaWaves * i;
+        *reinterpret_cast<uint4*>(tile + (idx >> 2) * C::TLD + (idx & 3) * 8) = v[i];
+    }
+}
+// the two steps in one (no prefetch)
+template <int HD>
+__device__ __forceinline__ void b3_load_rows(__bf16* tile, const __bf16* __restrict__ src) {
+    using C = B3Cfg<HD>;
+    constexpr int V8 = HD / 8;
+#pragma unroll
+    for (int idx = threadIdx.x; idx < C::BN * V8; idx += 64 * kSaWaves) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[idx];
+        *reinterpret_cast<uint4*>(tile + (idx / V8) * C::RLD + (idx % V8) * 8) = v;
+    }
+}
+template <int HD>
+__device__ __forceinline__ void b3_load_t(__bf16* tile, const __bf16* __restrict__ src) {
+    using C = B3Cfg<HD>;
+#pragma unroll
+    for (int idx = threadIdx.x; idx < C::NG * HD * 4; idx += 64 * kSaWaves) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[idx];
+        *reinterpret_cast<uint4*>(tile + (idx >> 2) * C::TLD + (idx & 3) * 8) = v;
+    }
+}
+// score product of tile t of a row-form tile with a wave's own rows (B operand in registers)
+template <int HD>
+__device__ __forceinline__ f32x4 b3_dot(const __bf16* th, const __bf16* tl, int t, const bf16x8 (&bh)[HD / 32], const bf16x8 (&bl)[HD / 32],
+                                        int j, int kk) {
+    using C = B3Cfg<HD>;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int at = (16 * t + j) * C::RLD + 8 * kk;
+#pragma unroll
+    for (int k = 0; k < C::KS; ++k)
+        acc = mma3(*reinterpret_cast<const bf16x8*>(th + at + 32 * k), *reinterpret_cast<const bf16x8*>(tl + at + 32 * k), bh[k], bl[k], acc);
+    return acc;
+}
+// second product: acc[ct] += T-form tile (group g, column 16 ct + j) . (wh, wl)
+template <int HD>
+__device__ __forceinline__ void b3_tacc(f32x4 (&acc)[HD / 16], const __bf16* th, const __bf16* tl, int g, const bf16x8& wh, const bf16x8& wl,
+                                        int j, int kk) {
+    using C = B3Cfg<HD>;
+#pragma unroll
+    for (int ct = 0; ct < C::CT; ++ct) {
+        const int at = (g * HD + 16 * ct + j) * C::TLD + 8 * kk;
+        acc[ct] = mma3(*reinterpret_cast<const bf16x8*>(th + at), *reinterpret_cast<const bf16x8*>(tl + at), wh, wl, acc[ct]);
+    }
+}
+template <int HD>
+__device__ __forceinline__ void b3_own_rows(bf16x8 (&h)[HD / 32], bf16x8 (&l)[HD / 32], const B3Form& f, size_t hoff, int row, int kk) {
+#pragma unroll
+    for (int k = 0; k < HD / 32; ++k) {
+        h[k] = *reinterpret_cast<const bf16x8*>(f.rh + hoff + (size_t)row * HD + 32 * k + 8 * kk);
+        l[k] = *reinterpret_cast<const bf16x8*>(f.rl + hoff + (size_t)row * HD + 32 * k + 8 * kk);
+    }
 }
 // two consecutive result tiles of a lane (rows 4 kk + e of tile 2g, then of tile 2g + 1) -> the B operand of a second product
 __device__ __forceinline__ void b3_split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
@@ -439,99 +546,138 @@ __device__ __forceinline__ void b3_split8(const f32x4& a, const f32x4& b, bf16x8
     }
 }
 __device__ __forceinline__ uint32_t pick4(const uint32_t (&v)[4], int i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
-// forward / dQ orientation (lane column = query q, four key tiles t): the four lanes of a quad share q / 4, so each draws
-// the block of ONE tile (t = its quad position) and the quad exchanges words: w[t] = word (q % 4) of tile t's block
-__device__ __forceinline__ void b3_words_q(const SaDrop& dr, int q, int n0, int kk, int lane, uint32_t (&w)[4]) {
-    const int lq = lane & 3;
-    const uint4 b = sa_block(dr, q >> 2, (n0 + 16 * lq + 4 * kk) >> 2);
-    const uint32_t own[4] = {b.x, b.y, b.z, b.w};
+// forward / dQ orientation (lane column = query q, NT key tiles): w[t] = word (q % 4) of the block of (q / 4, tile t's keys).
+// With four tiles per step the four lanes of a quad (same q / 4) each draw ONE tile's block and exchange words.
+template <int NT>
+__device__ __forceinline__ void b3_words_q(const SaDrop& dr, int q, int n0, int kk, int lane, uint32_t (&w)[NT]) {
+    if constexpr (NT == 4) {
+        const int lq = lane & 3;
+        const uint4 b = sa_block(dr, q >> 2, (n0 + 16 * lq + 4 * kk) >> 2);
+        const uint32_t own[4] = {b.x, b.y, b.z, b.w};
+        uint32_t got[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const uint32_t got = (uint32_t)__shfl_xor((int)pick4(own, lq ^ x), x);
+        for (int x = 0; x < 4; ++x) got[x] = (uint32_t)__shfl_xor((int)pick4(own, lq ^ x), x);     // = word lq of tile (lq ^ x)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (t == (lq ^ x)) w[t] = got;
+        for (int t = 0; t < 4; ++t) w[t] = pick4(got, t ^ lq);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = sa_word(sa_block(dr, q >> 2, (n0 + 16 * t + 4 * kk) >> 2), q & 3);
     }
 }
-// dK/dV orientation (lane column = key, four query tiles t, all four words of a block used by every lane of the quad):
-// quad lane t draws tile t's block, the quad reads it from there
-__device__ __forceinline__ void b3_blocks_key(const SaDrop& dr, int key, int q0, int kk, int lane, uint32_t (&w)[4][4]) {
-    const int lq = lane & 3;
-    const uint4 b = sa_block(dr, (q0 + 16 * lq + 4 * kk) >> 2, key >> 2);
+// dK/dV orientation (lane column = key, NT query tiles, all four words of a block used by every lane of the quad)
+template <int NT>
+__device__ __forceinline__ void b3_blocks_key(const SaDrop& dr, int key, int q0, int kk, int lane, uint32_t (&w)[NT][4]) {
+    if constexpr (NT == 4) {
+        const int lq = lane & 3;
+        const uint4 b = sa_block(dr, (q0 + 16 * lq + 4 * kk) >> 2, key >> 2);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int from = (lane & ~3) | t;
-        w[t][0] = (uint32_t)__shfl((int)b.x, from); w[t][1] = (uint32_t)__shfl((int)b.y, from);
-        w[t][2] = (uint32_t)__shfl((int)b.z, from); w[t][3] = (uint32_t)__shfl((int)b.w, from);
+        for (int t = 0; t < 4; ++t) {
+            const int from = (lane & ~3) | t;
+            w[t][0] = (uint32_t)__shfl((int)b.x, from); w[t][1] = (uint32_t)__shfl((int)b.y, from);
+            w[t][2] = (uint32_t)__shfl((int)b.z, from); w[t][3] = (uint32_t)__shfl((int)b.w, from);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint4 b = sa_block(dr, (q0 + 16 * t + 4 * kk) >> 2, key >> 2);
+            w[t][0] = b.x; w[t][1] = b.y; w[t][2] = b.z; w[t][3] = b.w;
+        }
     }
 }
 
-// src columns [col0 + 32 h, +32) of rows [32 bx, +32) -> row and / or T form (either pointer pair may be null)
+// src columns [col0 + HD h, +HD) of rows [32 bx, +32) -> row and / or T form (either pointer pair may be null)
+template <int HD>
 __global__ __launch_bounds__(256)
 void sa_b3_split_kernel(const float* __restrict__ src, int ld, int col0, int M, int Mp, __bf16* __restrict__ rh, __bf16* __restrict__ rl,
                         __bf16* __restrict__ th, __bf16* __restrict__ tl) {
     __shared__ __bf16 sh[2][32][36];
     const int h = blockIdx.y, H = gridDim.y, seq = blockIdx.z;
     const int rho = threadIdx.x >> 3, c4 = threadIdx.x & 7, row = blockIdx.x * 32 + rho;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < M) v = *reinterpret_cast<const float4*>(src + ((size_t)seq * M + row) * ld + col0 + 32 * h + 4 * c4);
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    bf16x4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { __bf16 a, b; split_bf16(x[e], a, b); hi[e] = a; lo[e] = b; }
     const size_t head = (size_t)seq * H + h;
-    if (rh) {
-        const size_t at = (head * Mp + row) * 32 + 4 * c4;
-        *reinterpret_cast<bf16x4*>(rh + at) = hi;
-        *reinterpret_cast<bf16x4*>(rl + at) = lo;
-    }
-    if (th) {
-        const int slot = ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);          // rho = 16 u + 4 kk + e
+    for (int cb = 0; cb < HD; cb += 32) {                    // 32 columns per round
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < M) v = *reinterpret_cast<const float4*>(src + ((size_t)seq * M + row) * ld + col0 + HD * h + cb + 4 * c4);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        bf16x4 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sh[0][4 * c4 + e][slot] = hi[e]; sh[1][4 * c4 + e][slot] = lo[e]; }
-        __syncthreads();
-        const int c = threadIdx.x >> 3, p4 = (threadIdx.x & 7) * 4;
-        const size_t at = ((head * (Mp / 32) + blockIdx.x) * 32 + c) * 32 + p4;
-        bf16x4 oh, ol;
+        for (int e = 0; e < 4; ++e) { __bf16 a, b; split_bf16(x[e], a, b); hi[e] = a; lo[e] = b; }
+        if (rh) {
+            const size_t at = (head * Mp + row) * HD + cb + 4 * c4;
+            *reinterpret_cast<bf16x4*>(rh + at) = hi;
+            *reinterpret_cast<bf16x4*>(rl + at) = lo;
+        }
+        if (th) {
+            const int slot = ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);      // rho = 16 u + 4 kk + e
+            __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { oh[e] = sh[0][c][p4 + e]; ol[e] = sh[1][c][p4 + e]; }
-        *reinterpret_cast<bf16x4*>(th + at) = oh;
-        *reinterpret_cast<bf16x4*>(tl + at) = ol;
+            for (int e = 0; e < 4; ++e) { sh[0][4 * c4 + e][slot] = hi[e]; sh[1][4 * c4 + e][slot] = lo[e]; }
+            __syncthreads();
+            const int c = threadIdx.x >> 3, p4 = (threadIdx.x & 7) * 4;
+            const size_t at = ((head * (Mp / 32) + blockIdx.x) * HD + cb + c) * 32 + p4;
+            bf16x4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oh[e] = sh[0][c][p4 + e]; ol[e] = sh[1][c][p4 + e]; }
+            *reinterpret_cast<bf16x4*>(th + at) = oh;
+            *reinterpret_cast<bf16x4*>(tl + at) = ol;
+        }
     }
 }
 
 // grid (Mp / 64, heads, sequences); Q, K in row form, V in T form
+template <int HD>
 __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, float* __restrict__ lse2, int M, int Mp, int d, float scale,
                           float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch) {
-    __shared__ __attribute__((aligned(16))) __bf16 sm[4 * kB3Tile];
-    __bf16 *kh = sm, *kl = sm + kB3Tile, *vh = sm + 2 * kB3Tile, *vl = sm + 3 * kB3Tile;
+    using C = B3Cfg<HD>;
+    __shared__ __attribute__((aligned(16))) __bf16 sm[2 * C::RTILE + 2 * C::TTILE];
+    __bf16 *kh = sm, *kl = sm + C::RTILE, *vh = sm + 2 * C::RTILE, *vl = vh + C::TTILE;
     const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
-    const size_t head = (size_t)seq * H + h, hoff = head * Mp * 32;
+    const size_t head = (size_t)seq * H + h, hoff = head * Mp * HD;
     o += (size_t)seq * M * d;
     lse2 += head * M;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const int q = blockIdx.x * 64 + 16 * wv + j;
     const SaDrop dr = sa_drop(drop_p, seed, offset, epoch, (int)head);
-    const bf16x8 qh = *reinterpret_cast<const bf16x8*>(Q.rh + hoff + (size_t)q * 32 + 8 * kk);
-    const bf16x8 ql = *reinterpret_cast<const bf16x8*>(Q.rl + hoff + (size_t)q * 32 + 8 * kk);
+    bf16x8 qh[C::KS], ql[C::KS];
+    b3_own_rows<HD>(qh, ql, Q, hoff, q, kk);
     const float c2 = scale * kLog2e;
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[C::CT];
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
-    for (int n0 = 0; n0 < M; n0 += 64) {
+    uint4 s_kh[B3Stage<HD>::RV], s_kl[B3Stage<HD>::RV], s_vh[B3Stage<HD>::TV], s_vl[B3Stage<HD>::TV];
+    auto stage = [&](int n0) __attribute__((always_inline)) {
+        b3_stage_rows<HD>(s_kh, K.rh + hoff + (size_t)n0 * HD);
+        b3_stage_rows<HD>(s_kl, K.rl + hoff + (size_t)n0 * HD);
+        b3_stage_t<HD>(s_vh, V.th + hoff + (size_t)n0 * HD);
+        b3_stage_t<HD>(s_vl, V.tl + hoff + (size_t)n0 * HD);
+    };
+    if (B3Stage<HD>::kPipe) stage(0);
+    for (int n0 = 0; n0 < M; n0 += C::BN) {
         __syncthreads();
-        b3_load(kh, K.rh + hoff + (size_t)n0 * 32);
-        b3_load(kl, K.rl + hoff + (size_t)n0 * 32);
-        b3_load(vh, V.th + hoff + (size_t)n0 * 32);
-        b3_load(vl, V.tl + hoff + (size_t)n0 * 32);
+        if constexpr (B3Stage<HD>::kPipe) {
+            b3_commit_rows<HD>(kh, s_kh);
+            b3_commit_rows<HD>(kl, s_kl);
+            b3_commit_t<HD>(vh, s_vh);
+            b3_commit_t<HD>(vl, s_vl);
+            if (n0 + C::BN < M) stage(n0 + C::BN);
+        } else {
+            b3_load_rows<HD>(kh, K.rh + hoff + (size_t)n0 * HD);
+            b3_load_rows<HD>(kl, K.rl + hoff + (size_t)n0 * HD);
+            b3_load_t<HD>(vh, V.th + hoff + (size_t)n0 * HD);
+            b3_load_t<HD>(vl, V.tl + hoff + (size_t)n0 * HD);
+        }
         __syncthreads();
-        f32x4 s[4];
+        f32x4 s[C::NT];
         float mx = m;
+        const bool edge = n0 + C::BN > M;                    // uniform: only the last step has keys past the end
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            s[t] = mma3(b3_frag(kh, 16 * t + j, kk), b3_frag(kl, 16 * t + j, kk), qh, ql, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int t = 0; t < C::NT; ++t) {
+            s[t] = b3_dot<HD>(kh, kl, t, qh, ql, j, kk) * c2;
+            if (edge) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = (n0 + 16 * t + 4 * kk + r < M) ? s[t][r] * c2 : -INFINITY;
+                for (int r = 0; r < 4; ++r) s[t][r] = (n0 + 16 * t + 4 * kk + r < M) ? s[t][r] : -INFINITY;
+            }
             mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -539,11 +685,12 @@ void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, f
         const float alpha = fast_exp2(m - mx);
         m = mx;
         l *= alpha;
-        acc[0] *= alpha; acc[1] *= alpha;
-        uint32_t w[4];
-        if (dr.thr) b3_words_q(dr, q, n0, kk, lane, w);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int c = 0; c < C::CT; ++c) acc[c] *= alpha;
+        uint32_t w[C::NT];
+        if (dr.thr) b3_words_q<C::NT>(dr, q, n0, kk, lane, w);
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s[t][r] = fast_exp2(s[t][r] - mx); l += s[t][r]; }
             if (dr.thr) {
@@ -552,12 +699,10 @@ void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, f
             }
         }
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < C::NG; ++g) {
             bf16x8 ph, pl;
             b3_split8(s[2 * g], s[2 * g + 1], ph, pl);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                acc[ct] = mma3(b3_frag(vh, 32 * g + 16 * ct + j, kk), b3_frag(vl, 32 * g + 16 * ct + j, kk), ph, pl, acc[ct]);
+            b3_tacc<HD>(acc, vh, vl, g, ph, pl, j, kk);
         }
     }
     l += __shfl_xor(l, 16);
@@ -565,22 +710,81 @@ void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, f
     if (q < M) {
         const float inv = 1.0f / l;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            *reinterpret_cast<float4*>(o + (size_t)q * d + h * 32 + 16 * c + 4 * kk) =
+        for (int c = 0; c < C::CT; ++c)
+            *reinterpret_cast<float4*>(o + (size_t)q * d + h * HD + 16 * c + 4 * kk) =
                 make_float4(acc[c][0] * inv, acc[c][1] * inv, acc[c][2] * inv, acc[c][3] * inv);
         if (kk == 0) lse2[q] = m + __builtin_amdgcn_logf(l);
     }
 }
 
+// the returned map of the one-head layer on the same arithmetic: map[q][key] = exp2(s - lse2[q]); key steps split over grid.y
+template <int HD>
+__global__ __launch_bounds__(64 * kSaWaves)
+void bag_sa_b3_map_kernel(B3Form Q, B3Form K, const float* __restrict__ lse2, float* __restrict__ map, int M, int Mp, float scale) {
+    using C = B3Cfg<HD>;
+    __shared__ __attribute__((aligned(16))) __bf16 sm[2 * C::RTILE];
+    __bf16 *kh = sm, *kl = sm + C::RTILE;
+    const int seq = blockIdx.z;
+    const size_t hoff = (size_t)seq * Mp * HD;
+    lse2 += (size_t)seq * M;
+    map += (size_t)seq * M * M;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    const int q = blockIdx.x * 64 + 16 * wv + j;
+    bf16x8 qh[C::KS], ql[C::KS];
+    b3_own_rows<HD>(qh, ql, Q, hoff, q, kk);
+    const float ls = q < M ? lse2[q] : 0.f, c2 = scale * kLog2e;
+    const int nblk = (M + C::BN - 1) / C::BN, per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    const bool vec = (M & 3) == 0;
+    uint4 s_kh[B3Stage<HD>::RV], s_kl[B3Stage<HD>::RV];
+    if (B3Stage<HD>::kPipe && b0 < b1) {
+        b3_stage_rows<HD>(s_kh, K.rh + hoff + (size_t)b0 * C::BN * HD);
+        b3_stage_rows<HD>(s_kl, K.rl + hoff + (size_t)b0 * C::BN * HD);
+    }
+    for (int b = b0; b < b1; ++b) {
+        const int n0 = b * C::BN;
+        __syncthreads();
+        if constexpr (B3Stage<HD>::kPipe) {
+            b3_commit_rows<HD>(kh, s_kh);
+            b3_commit_rows<HD>(kl, s_kl);
+            if (b + 1 < b1) {
+                b3_stage_rows<HD>(s_kh, K.rh + hoff + (size_t)(n0 + C::BN) * HD);
+                b3_stage_rows<HD>(s_kl, K.rl + hoff + (size_t)(n0 + C::BN) * HD);
+            }
+        } else {
+            b3_load_rows<HD>(kh, K.rh + hoff + (size_t)n0 * HD);
+            b3_load_rows<HD>(kl, K.rl + hoff + (size_t)n0 * HD);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            const f32x4 s = b3_dot<HD>(kh, kl, t, qh, ql, j, kk) * c2;
+            const int key = n0 + 16 * t + 4 * kk;
+            if (q < M) {
+                float* dst = map + (size_t)q * M + key;
+                if (vec && key + 3 < M) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(fast_exp2(s[0] - ls), fast_exp2(s[1] - ls), fast_exp2(s[2] - ls), fast_exp2(s[3] - ls));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key + r < M) dst[r] = fast_exp2(s[r] - ls);
+                }
+            }
+        }
+    }
+}
+
 // dQ (+ delta): Q, dO row form (the wave's own rows); K, V row form and K T form streamed
+template <int HD>
 __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_b3_dq_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* __restrict__ o, const float* __restrict__ d_o,
                          const float* __restrict__ lse2, float* __restrict__ dqkv, float* __restrict__ delta, int M, int Mp, int d,
                          float scale, float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch) {
-    __shared__ __attribute__((aligned(16))) __bf16 sm[6 * kB3Tile];
-    __bf16 *kh = sm, *kl = sm + kB3Tile, *vh = sm + 2 * kB3Tile, *vl = sm + 3 * kB3Tile, *kth = sm + 4 * kB3Tile, *ktl = sm + 5 * kB3Tile;
+    using C = B3Cfg<HD>;
+    __shared__ __attribute__((aligned(16))) __bf16 sm[4 * C::RTILE + 2 * C::TTILE];
+    __bf16 *kh = sm, *kl = sm + C::RTILE, *vh = sm + 2 * C::RTILE, *vl = sm + 3 * C::RTILE, *kth = sm + 4 * C::RTILE, *ktl = kth + C::TTILE;
     const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
-    const size_t head = (size_t)seq * H + h, hoff = head * Mp * 32;
+    const size_t head = (size_t)seq * H + h, hoff = head * Mp * HD;
     dqkv += (size_t)seq * M * 3 * d;
     o += (size_t)seq * M * d;
     d_o += (size_t)seq * M * d;
@@ -589,113 +793,165 @@ void bag_sa_b3_dq_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* _
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const int q = blockIdx.x * 64 + 16 * wv + j;
     const SaDrop dr = sa_drop(drop_p, seed, offset, epoch, (int)head);
-    const bf16x8 qh = *reinterpret_cast<const bf16x8*>(Q.rh + hoff + (size_t)q * 32 + 8 * kk);
-    const bf16x8 ql = *reinterpret_cast<const bf16x8*>(Q.rl + hoff + (size_t)q * 32 + 8 * kk);
-    const bf16x8 doh = *reinterpret_cast<const bf16x8*>(DO.rh + hoff + (size_t)q * 32 + 8 * kk);
-    const bf16x8 dol = *reinterpret_cast<const bf16x8*>(DO.rl + hoff + (size_t)q * 32 + 8 * kk);
+    bf16x8 qh[C::KS], ql[C::KS], doh[C::KS], dol[C::KS];
+    b3_own_rows<HD>(qh, ql, Q, hoff, q, kk);
+    b3_own_rows<HD>(doh, dol, DO, hoff, q, kk);
     float dl = 0.f;
     if (q < M) {
-        const float* op = o + (size_t)q * d + h * 32 + 8 * kk;
-        const float* gp = d_o + (size_t)q * d + h * 32 + 8 * kk;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dl += op[e] * gp[e];
+        for (int k = 0; k < C::KS; ++k) {
+            const float* op = o + (size_t)q * d + h * HD + 32 * k + 8 * kk;
+            const float* gp = d_o + (size_t)q * d + h * HD + 32 * k + 8 * kk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += op[e] * gp[e];
+        }
     }
     dl += __shfl_xor(dl, 16);
     dl += __shfl_xor(dl, 32);
     const float ls = q < M ? lse2[q] : INFINITY;
     if (q < M && kk == 0) delta[q] = dl;
     const float c2 = scale * kLog2e;
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int n0 = 0; n0 < M; n0 += 64) {
-        __syncthreads();
-        b3_load(kh, K.rh + hoff + (size_t)n0 * 32);
-        b3_load(kl, K.rl + hoff + (size_t)n0 * 32);
-        b3_load(vh, V.rh + hoff + (size_t)n0 * 32);
-        b3_load(vl, V.rl + hoff + (size_t)n0 * 32);
-        b3_load(kth, K.th + hoff + (size_t)n0 * 32);
-        b3_load(ktl, K.tl + hoff + (size_t)n0 * 32);
-        __syncthreads();
-        uint32_t w[4];
-        if (dr.thr) b3_words_q(dr, q, n0, kk, lane, w);
-        f32x4 ds[4];
+    f32x4 acc[C::CT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 s = mma3(b3_frag(kh, 16 * t + j, kk), b3_frag(kl, 16 * t + j, kk), qh, ql, f32x4{0.f, 0.f, 0.f, 0.f});
-            f32x4 dp = mma3(b3_frag(vh, 16 * t + j, kk), b3_frag(vl, 16 * t + j, kk), doh, dol, f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int c = 0; c < C::CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 s_kh[B3Stage<HD>::RV], s_kl[B3Stage<HD>::RV], s_vh[B3Stage<HD>::RV], s_vl[B3Stage<HD>::RV], s_th[B3Stage<HD>::TV], s_tl[B3Stage<HD>::TV];
+    auto stage = [&](int n0) __attribute__((always_inline)) {
+        b3_stage_rows<HD>(s_kh, K.rh + hoff + (size_t)n0 * HD);
+        b3_stage_rows<HD>(s_kl, K.rl + hoff + (size_t)n0 * HD);
+        b3_stage_rows<HD>(s_vh, V.rh + hoff + (size_t)n0 * HD);
+        b3_stage_rows<HD>(s_vl, V.rl + hoff + (size_t)n0 * HD);
+        b3_stage_t<HD>(s_th, K.th + hoff + (size_t)n0 * HD);
+        b3_stage_t<HD>(s_tl, K.tl + hoff + (size_t)n0 * HD);
+    };
+    if (B3Stage<HD>::kPipe) stage(0);
+    for (int n0 = 0; n0 < M; n0 += C::BN) {
+        __syncthreads();
+        if constexpr (B3Stage<HD>::kPipe) {
+            b3_commit_rows<HD>(kh, s_kh);
+            b3_commit_rows<HD>(kl, s_kl);
+            b3_commit_rows<HD>(vh, s_vh);
+            b3_commit_rows<HD>(vl, s_vl);
+            b3_commit_t<HD>(kth, s_th);
+            b3_commit_t<HD>(ktl, s_tl);
+            if (n0 + C::BN < M) stage(n0 + C::BN);
+        } else {
+            b3_load_rows<HD>(kh, K.rh + hoff + (size_t)n0 * HD);
+            b3_load_rows<HD>(kl, K.rl + hoff + (size_t)n0 * HD);
+            b3_load_rows<HD>(vh, V.rh + hoff + (size_t)n0 * HD);
+            b3_load_rows<HD>(vl, V.rl + hoff + (size_t)n0 * HD);
+            b3_load_t<HD>(kth, K.th + hoff + (size_t)n0 * HD);
+            b3_load_t<HD>(ktl, K.tl + hoff + (size_t)n0 * HD);
+        }
+        __syncthreads();
+        uint32_t w[C::NT];
+        if (dr.thr) b3_words_q<C::NT>(dr, q, n0, kk, lane, w);
+        const bool edge = n0 + C::BN > M;
+        f32x4 ds[C::NT];
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            const f32x4 s = b3_dot<HD>(kh, kl, t, qh, ql, j, kk);
+            f32x4 dp = b3_dot<HD>(vh, vl, t, doh, dol, j, kk);
             if (dr.thr) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dp[r] *= sa_keep(dr, w[t], r);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = (n0 + 16 * t + 4 * kk + r < M) ? fast_exp2(s[r] * c2 - ls) : 0.f;
+                float p = fast_exp2(s[r] * c2 - ls);
+                if (edge) p = (n0 + 16 * t + 4 * kk + r < M) ? p : 0.f;
                 ds[t][r] = p * (dp[r] - dl);
             }
         }
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < C::NG; ++g) {
             bf16x8 dh, dlo;
             b3_split8(ds[2 * g], ds[2 * g + 1], dh, dlo);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                acc[ct] = mma3(b3_frag(kth, 32 * g + 16 * ct + j, kk), b3_frag(ktl, 32 * g + 16 * ct + j, kk), dh, dlo, acc[ct]);
+            b3_tacc<HD>(acc, kth, ktl, g, dh, dlo, j, kk);
         }
     }
     if (q < M) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            *reinterpret_cast<float4*>(dqkv + (size_t)q * 3 * d + h * 32 + 16 * c + 4 * kk) =
+        for (int c = 0; c < C::CT; ++c)
+            *reinterpret_cast<float4*>(dqkv + (size_t)q * 3 * d + h * HD + 16 * c + 4 * kk) =
                 make_float4(acc[c][0] * scale, acc[c][1] * scale, acc[c][2] * scale, acc[c][3] * scale);
     }
 }
 
 // dK, dV: K, V row form (the wave's own rows); Q, dO row and T forms streamed
+template <int HD>
 __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* __restrict__ lse2, const float* __restrict__ delta,
                           float* __restrict__ dqkv, int M, int Mp, int d, float scale, float drop_p, unsigned long long seed,
                           unsigned long long offset, const unsigned long long* epoch) {
-    __shared__ __attribute__((aligned(16))) __bf16 sm[8 * kB3Tile];
-    __shared__ __attribute__((aligned(16))) float st[128];
-    __bf16 *qh = sm, *ql = sm + kB3Tile, *gh = sm + 2 * kB3Tile, *gl = sm + 3 * kB3Tile;
-    __bf16 *qth = sm + 4 * kB3Tile, *qtl = sm + 5 * kB3Tile, *gth = sm + 6 * kB3Tile, *gtl = sm + 7 * kB3Tile;
-    float *ls_t = st, *dl_t = st + 64;
+    using C = B3Cfg<HD>;
+    __shared__ __attribute__((aligned(16))) __bf16 sm[4 * C::RTILE + 4 * C::TTILE];
+    __shared__ __attribute__((aligned(16))) float st[2 * C::BN];
+    __bf16 *qh = sm, *ql = sm + C::RTILE, *gh = sm + 2 * C::RTILE, *gl = sm + 3 * C::RTILE;
+    __bf16 *qth = sm + 4 * C::RTILE, *qtl = qth + C::TTILE, *gth = qth + 2 * C::TTILE, *gtl = qth + 3 * C::TTILE;
+    float *ls_t = st, *dl_t = st + C::BN;
     const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
-    const size_t head = (size_t)seq * H + h, hoff = head * Mp * 32;
+    const size_t head = (size_t)seq * H + h, hoff = head * Mp * HD;
     dqkv += (size_t)seq * M * 3 * d;
     lse2 += head * M;
     delta += head * M;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const int key = blockIdx.x * 64 + 16 * wv + j;
     const SaDrop dr = sa_drop(drop_p, seed, offset, epoch, (int)head);
-    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(K.rh + hoff + (size_t)key * 32 + 8 * kk);
-    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(K.rl + hoff + (size_t)key * 32 + 8 * kk);
-    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(V.rh + hoff + (size_t)key * 32 + 8 * kk);
-    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(V.rl + hoff + (size_t)key * 32 + 8 * kk);
+    bf16x8 kh[C::KS], kl[C::KS], vh[C::KS], vl[C::KS];
+    b3_own_rows<HD>(kh, kl, K, hoff, key, kk);
+    b3_own_rows<HD>(vh, vl, V, hoff, key, kk);
     const float c2 = scale * kLog2e;
-    f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int q0 = 0; q0 < M; q0 += 64) {
+    f32x4 dk[C::CT], dv[C::CT];
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    uint4 s_qh[B3Stage<HD>::RV], s_ql[B3Stage<HD>::RV], s_gh[B3Stage<HD>::RV], s_gl[B3Stage<HD>::RV];
+    uint4 s_qth[B3Stage<HD>::TV], s_qtl[B3Stage<HD>::TV], s_gth[B3Stage<HD>::TV], s_gtl[B3Stage<HD>::TV];
+    auto stage = [&](int q0) __attribute__((always_inline)) {
+        b3_stage_rows<HD>(s_qh, Q.rh + hoff + (size_t)q0 * HD);
+        b3_stage_rows<HD>(s_ql, Q.rl + hoff + (size_t)q0 * HD);
+        b3_stage_rows<HD>(s_gh, DO.rh + hoff + (size_t)q0 * HD);
+        b3_stage_rows<HD>(s_gl, DO.rl + hoff + (size_t)q0 * HD);
+        b3_stage_t<HD>(s_qth, Q.th + hoff + (size_t)q0 * HD);
+        b3_stage_t<HD>(s_qtl, Q.tl + hoff + (size_t)q0 * HD);
+        b3_stage_t<HD>(s_gth, DO.th + hoff + (size_t)q0 * HD);
+        b3_stage_t<HD>(s_gtl, DO.tl + hoff + (size_t)q0 * HD);
+    };
+    if (B3Stage<HD>::kPipe) stage(0);
+    for (int q0 = 0; q0 < M; q0 += C::BN) {
         __syncthreads();
-        b3_load(qh, Q.rh + hoff + (size_t)q0 * 32);
-        b3_load(ql, Q.rl + hoff + (size_t)q0 * 32);
-        b3_load(gh, DO.rh + hoff + (size_t)q0 * 32);
-        b3_load(gl, DO.rl + hoff + (size_t)q0 * 32);
-        b3_load(qth, Q.th + hoff + (size_t)q0 * 32);
-        b3_load(qtl, Q.tl + hoff + (size_t)q0 * 32);
-        b3_load(gth, DO.th + hoff + (size_t)q0 * 32);
-        b3_load(gtl, DO.tl + hoff + (size_t)q0 * 32);
-        if (threadIdx.x < 64) {
+        if constexpr (B3Stage<HD>::kPipe) {
+            b3_commit_rows<HD>(qh, s_qh);
+            b3_commit_rows<HD>(ql, s_ql);
+            b3_commit_rows<HD>(gh, s_gh);
+            b3_commit_rows<HD>(gl, s_gl);
+            b3_commit_t<HD>(qth, s_qth);
+            b3_commit_t<HD>(qtl, s_qtl);
+            b3_commit_t<HD>(gth, s_gth);
+            b3_commit_t<HD>(gtl, s_gtl);
+            if (q0 + C::BN < M) stage(q0 + C::BN);
+        } else {
+            b3_load_rows<HD>(qh, Q.rh + hoff + (size_t)q0 * HD);
+            b3_load_rows<HD>(ql, Q.rl + hoff + (size_t)q0 * HD);
+            b3_load_rows<HD>(gh, DO.rh + hoff + (size_t)q0 * HD);
+            b3_load_rows<HD>(gl, DO.rl + hoff + (size_t)q0 * HD);
+            b3_load_t<HD>(qth, Q.th + hoff + (size_t)q0 * HD);
+            b3_load_t<HD>(qtl, Q.tl + hoff + (size_t)q0 * HD);
+            b3_load_t<HD>(gth, DO.th + hoff + (size_t)q0 * HD);
+            b3_load_t<HD>(gtl, DO.tl + hoff + (size_t)q0 * HD);
+        }
+        if (threadIdx.x < C::BN) {
             const int qq = q0 + threadIdx.x;
             ls_t[threadIdx.x] = qq < M ? lse2[qq] : INFINITY;
             dl_t[threadIdx.x] = qq < M ? delta[qq] : 0.f;
         }
         __syncthreads();
-        uint32_t w[4][4];
-        if (dr.thr) b3_blocks_key(dr, key, q0, kk, lane, w);
-        f32x4 pd[4], ds[4];
+        uint32_t w[C::NT][4];
+        if (dr.thr) b3_blocks_key<C::NT>(dr, key, q0, kk, lane, w);
+        f32x4 pd[C::NT], ds[C::NT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 s = mma3(b3_frag(qh, 16 * t + j, kk), b3_frag(ql, 16 * t + j, kk), kh, kl, f32x4{0.f, 0.f, 0.f, 0.f});
-            f32x4 dp = mma3(b3_frag(gh, 16 * t + j, kk), b3_frag(gl, 16 * t + j, kk), vh, vl, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int t = 0; t < C::NT; ++t) {
+            const f32x4 s = b3_dot<HD>(qh, ql, t, kh, kl, j, kk);
+            const f32x4 dp = b3_dot<HD>(gh, gl, t, vh, vl, j, kk);
             const float4 ls = *reinterpret_cast<const float4*>(ls_t + 16 * t + 4 * kk);
             const float4 dl = *reinterpret_cast<const float4*>(dl_t + 16 * t + 4 * kk);
             const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
@@ -708,21 +964,18 @@ void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* 
             }
         }
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < C::NG; ++g) {
             bf16x8 ph, pl, sh_, sl_;
             b3_split8(pd[2 * g], pd[2 * g + 1], ph, pl);
             b3_split8(ds[2 * g], ds[2 * g + 1], sh_, sl_);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                dv[ct] = mma3(b3_frag(gth, 32 * g + 16 * ct + j, kk), b3_frag(gtl, 32 * g + 16 * ct + j, kk), ph, pl, dv[ct]);
-                dk[ct] = mma3(b3_frag(qth, 32 * g + 16 * ct + j, kk), b3_frag(qtl, 32 * g + 16 * ct + j, kk), sh_, sl_, dk[ct]);
-            }
+            b3_tacc<HD>(dv, gth, gtl, g, ph, pl, j, kk);
+            b3_tacc<HD>(dk, qth, qtl, g, sh_, sl_, j, kk);
         }
     }
     if (key < M) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float* at = dqkv + (size_t)key * 3 * d + h * 32 + 16 * c + 4 * kk;
+        for (int c = 0; c < C::CT; ++c) {
+            float* at = dqkv + (size_t)key * 3 * d + h * HD + 16 * c + 4 * kk;
             *reinterpret_cast<float4*>(at + d) = make_float4(dk[c][0] * scale, dk[c][1] * scale, dk[c][2] * scale, dk[c][3] * scale);
             *reinterpret_cast<float4*>(at + 2 * d) = make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]);
         }
@@ -730,18 +983,60 @@ void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* 
 }
 
 inline int b3_mp(int M) { return (M + 63) / 64 * 64; }
-inline bool b3_applies(int d, int H) { return g_sa_b3 && H > 1 && d == 32 * H; }
-// one operand's forms inside a workspace of bf16: [rh | rl | th | tl], each n_seq * H * Mp * 32 elements
+// head widths of the three-term path: 32 with several heads (encoder layers), 256 (the one-head layer of the medium model)
+inline bool b3_geometry(int d, int H) { return (H > 1 && d == 32 * H) || (H == 1 && d == 256); }
+inline bool b3_applies(int d, int H) { return g_sa_b3 && b3_geometry(d, H); }
+// one operand's forms inside a workspace of bf16: [rh | rl | th | tl], each n_seq * Mp * d elements
 inline B3Form b3_form(__bf16* base, int idx, size_t each) {
     __bf16* p = base + (size_t)idx * 4 * each;
     return B3Form{p, p + each, p + 2 * each, p + 3 * each};
 }
-inline int b3_split(const float* src, int ld, int col0, int n_seq, int M, int H, const B3Form& f, bool rows, bool tform, hipStream_t s) {
+template <int HD>
+int b3_split(const float* src, int ld, int col0, int n_seq, int M, int H, const B3Form& f, bool rows, bool tform, hipStream_t s) {
     const int Mp = b3_mp(M);
-    sa_b3_split_kernel<<<dim3(Mp / 32, H, n_seq), 256, 0, s>>>(src, ld, col0, M, Mp, rows ? const_cast<__bf16*>(f.rh) : nullptr,
-                                                             rows ? const_cast<__bf16*>(f.rl) : nullptr,
-                                                             tform ? const_cast<__bf16*>(f.th) : nullptr,
-                                                             tform ? const_cast<__bf16*>(f.tl) : nullptr);
+    sa_b3_split_kernel<HD><<<dim3(Mp / 32, H, n_seq), 256, 0, s>>>(src, ld, col0, M, Mp, rows ? const_cast<__bf16*>(f.rh) : nullptr,
+                                                                 rows ? const_cast<__bf16*>(f.rl) : nullptr,
+                                                                 tform ? const_cast<__bf16*>(f.th) : nullptr,
+                                                                 tform ? const_cast<__bf16*>(f.tl) : nullptr);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+template <int HD>
+int b3_forward(const float* qkv, int n_seq, int M, int d, int H, float drop_p, unsigned long long seed, unsigned long long offset,
+               const unsigned long long* epoch, float* o, float* saved, float* map, hipStream_t s) {
+    const int Mp = b3_mp(M);
+    const size_t each = (size_t)n_seq * Mp * d;
+    __bf16* forms = reinterpret_cast<__bf16*>(saved + ((size_t)n_seq * H * M + 3) / 4 * 4);
+    const B3Form Q = b3_form(forms, 0, each), K = b3_form(forms, 1, each), V = b3_form(forms, 2, each);
+    if (int rc = b3_split<HD>(qkv, 3 * d, 0, n_seq, M, H, Q, true, true, s)) return rc;
+    if (int rc = b3_split<HD>(qkv, 3 * d, d, n_seq, M, H, K, true, true, s)) return rc;
+    if (int rc = b3_split<HD>(qkv, 3 * d, 2 * d, n_seq, M, H, V, true, true, s)) return rc;
+    const float scale = 1.0f / sqrtf((float)HD);
+    bag_sa_b3_fwd_kernel<HD><<<dim3(Mp / 64, H, n_seq), 64 * kSaWaves, 0, s>>>(Q, K, V, o, saved, M, Mp, d, scale, drop_p, seed, offset, epoch);
+    MPO_LAUNCH_CHECK();
+    if (map) {
+        const int qb = Mp / 64, nblk = (M + B3Cfg<HD>::BN - 1) / B3Cfg<HD>::BN;
+        int split = (2048 + qb - 1) / qb;
+        if (split > nblk) split = nblk;
+        bag_sa_b3_map_kernel<HD><<<dim3(qb, split, n_seq), 64 * kSaWaves, 0, s>>>(Q, K, saved, map, M, Mp, scale);
+        MPO_LAUNCH_CHECK();
+    }
+    return 0;
+}
+template <int HD>
+int b3_backward(const float* o, const float* saved, const float* d_o, int n_seq, int M, int d, int H, float drop_p, unsigned long long seed,
+                unsigned long long offset, const unsigned long long* epoch, float* dqkv, float* scratch, hipStream_t s) {
+    const int Mp = b3_mp(M);
+    const size_t each = (size_t)n_seq * Mp * d, lse_floats = ((size_t)n_seq * H * M + 3) / 4 * 4;
+    __bf16* forms = reinterpret_cast<__bf16*>(const_cast<float*>(saved) + lse_floats);
+    const B3Form Q = b3_form(forms, 0, each), K = b3_form(forms, 1, each), V = b3_form(forms, 2, each);
+    const B3Form DO = b3_form(reinterpret_cast<__bf16*>(scratch + lse_floats), 0, each);
+    if (int rc = b3_split<HD>(d_o, d, 0, n_seq, M, H, DO, true, true, s)) return rc;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const dim3 grid(Mp / 64, H, n_seq);
+    bag_sa_b3_dq_kernel<HD><<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, o, d_o, saved, dqkv, scratch, M, Mp, d, scale, drop_p, seed, offset, epoch);
+    MPO_LAUNCH_CHECK();
+    bag_sa_b3_dkv_kernel<HD><<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, saved, scratch, dqkv, M, Mp, d, scale, drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }
@@ -760,13 +1055,13 @@ int mpo_bag_sa_set_bf16x3(int enabled) {
 // (Q rows, K rows + T, V rows + T: 3 operands x 4 arrays of bf16), which the backward reads again
 size_t mpo_bag_sa_saved_floats(int n_seq, int M, int d, int H) {
     size_t n = ((size_t)n_seq * H * M + 3) / 4 * 4;
-    if (H > 1 && d == 32 * H) n += 3 * 4 * ((size_t)n_seq * H * b3_mp(M) * 32) / 2;
+    if (b3_geometry(d, H)) n += 3 * 4 * ((size_t)n_seq * b3_mp(M) * d) / 2;
     return n;
 }
 // floats of backward scratch: delta + (three-term path) the four forms of dO
 size_t mpo_bag_sa_bwd_floats(int n_seq, int M, int d, int H) {
     size_t n = ((size_t)n_seq * H * M + 3) / 4 * 4;
-    if (H > 1 && d == 32 * H) n += 4 * ((size_t)n_seq * H * b3_mp(M) * 32) / 2;
+    if (b3_geometry(d, H)) n += 4 * ((size_t)n_seq * b3_mp(M) * d) / 2;
     return n;
 }
 
@@ -780,17 +1075,8 @@ int mpo_launch_bag_sa_fwd(const float* qkv, int n_seq, int M, int d, int H, floa
     MPO_CHECK(sa_al16(qkv) && sa_al16(o) && sa_al16(saved) && (map == nullptr || sa_al16(map)), "bag self-attention: buffers must be 16-byte aligned");
     float* lse2 = saved;
     if (b3_applies(d, H)) {
-        const int Mp = b3_mp(M);
-        const size_t each = (size_t)n_seq * H * Mp * 32;
-        __bf16* forms = reinterpret_cast<__bf16*>(saved + ((size_t)n_seq * H * M + 3) / 4 * 4);
-        const B3Form Q = b3_form(forms, 0, each), K = b3_form(forms, 1, each), V = b3_form(forms, 2, each);
-        if (int rc = b3_split(qkv, 3 * d, 0, n_seq, M, H, Q, true, true, s)) return rc;
-        if (int rc = b3_split(qkv, 3 * d, d, n_seq, M, H, K, true, true, s)) return rc;
-        if (int rc = b3_split(qkv, 3 * d, 2 * d, n_seq, M, H, V, true, true, s)) return rc;
-        bag_sa_b3_fwd_kernel<<<dim3(Mp / 64, H, n_seq), 64 * kSaWaves, 0, s>>>(Q, K, V, o, lse2, M, Mp, d, 1.0f / sqrtf(32.0f), drop_p, seed,
-                                                                              offset, epoch);
-        MPO_LAUNCH_CHECK();
-        return 0;
+        if (hd == 32) return b3_forward<32>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, saved, map, s);
+        return b3_forward<256>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, saved, map, s);
     }
     switch (hd) {
         case 16: return sa_forward<16>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
@@ -813,19 +1099,8 @@ int mpo_launch_bag_sa_bwd(const float* qkv, const float* o, const float* saved, 
     const float* lse2 = saved;
     float* delta = scratch;
     if (b3_applies(d, H)) {
-        const int Mp = b3_mp(M);
-        const size_t each = (size_t)n_seq * H * Mp * 32, lse_floats = ((size_t)n_seq * H * M + 3) / 4 * 4;
-        __bf16* forms = reinterpret_cast<__bf16*>(const_cast<float*>(saved) + lse_floats);
-        const B3Form Q = b3_form(forms, 0, each), K = b3_form(forms, 1, each), V = b3_form(forms, 2, each);
-        const B3Form DO = b3_form(reinterpret_cast<__bf16*>(scratch + lse_floats), 0, each);
-        if (int rc = b3_split(d_o, d, 0, n_seq, M, H, DO, true, true, s)) return rc;
-        const float scale = 1.0f / sqrtf(32.0f);
-        const dim3 grid(Mp / 64, H, n_seq);
-        bag_sa_b3_dq_kernel<<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, o, d_o, lse2, dqkv, delta, M, Mp, d, scale, drop_p, seed, offset, epoch);
-        MPO_LAUNCH_CHECK();
-        bag_sa_b3_dkv_kernel<<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, lse2, delta, dqkv, M, Mp, d, scale, drop_p, seed, offset, epoch);
-        MPO_LAUNCH_CHECK();
-        return 0;
+        if (hd == 32) return b3_backward<32>(o, saved, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, scratch, s);
+        return b3_backward<256>(o, saved, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, scratch, s);
     }
     switch (hd) {
         case 16: return sa_backward<16>(qkv, o, lse2, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, delta, s);

@@ -46,9 +46,10 @@ CASES = [  # n_bags, M, d, heads, q gain
 
 
 def _b3_modes(d, heads):
-    """Several heads of width 32 run on three-term bf16 MFMAs by default (~16 mantissa bits per operand); the verification hook
-    keeps them on the fp32 kernels.  -> [(hook value, output bar, gradient bar)]"""
-    return [(1, 1e-4, 1e-3), (0, 1e-5, 1e-4)] if heads > 1 and d == 32 * heads else [(1, 1e-5, 1e-4)]
+    """Heads of width 32 (several) and 256 (one) run on three-term bf16 MFMAs by default (~16 mantissa bits per operand); the
+    verification hook keeps them on the fp32 kernels.  -> [(hook value, output bar, gradient bar)]"""
+    b3 = (heads > 1 and d == 32 * heads) or (heads == 1 and d == 256)
+    return [(1, 1e-4, 1e-3), (0, 1e-5, 1e-4)] if b3 else [(1, 1e-5, 1e-4)]
 
 
 class bf16x3:
@@ -83,15 +84,16 @@ def test_attention_core_equals_torch(dev, n, m, d, heads, gain):
         for part in range(3):                                  # dq, dk, dv separately: none hides behind a larger one
             sl = slice(part * d, (part + 1) * d)
             assert relmax(x.grad[..., sl], xr.grad[..., sl], part_scale(xr.grad)(sl)) < grad_bar, (hook, part)
-    if heads == 1:
-        assert amap.shape == (n, m, m)
-        ref = p_r[:, 0].detach()
-        big = ref > 1e-30
-        err = ((amap.double().cpu() - ref).abs() / ref.clamp_min(1e-30))[big].max().item()
-        assert err < 1e-3, err                                 # north-star bar on maps: elementwise relative
-        assert float((amap.sum(-1) - 1).abs().max()) < 1e-5
-    else:
-        assert amap is None
+        if heads == 1:
+            assert amap.shape == (n, m, m)
+            ref = p_r[:, 0].detach()
+            big = ref > 1e-30
+            err = ((amap.double().cpu() - ref).abs() / ref.clamp_min(1e-30))[big].max().item()
+            print(f"[self-attention map] M={m} d={d} gain={gain} mode={hook}: max relative error {err:.2e}")
+            assert err < 1e-3, (hook, err)                     # north-star bar on maps: elementwise relative, both arithmetics
+            assert float((amap.sum(-1) - 1).abs().max()) < 1e-4
+        else:
+            assert amap is None
 
 
 def _recover_keep(dev, qkv, heads, p, offset):
