@@ -429,8 +429,11 @@ template <int HD> struct B3Cfg {
     static constexpr int NG = BN / 32;                       // 32-row groups per step
     static constexpr int KS = HD / 32;                       // MFMA k-steps of a score product
     static constexpr int CT = HD / 16;                       // 16-column tiles of the head dimension
-    static constexpr int RLD = HD + 8;                       // LDS row stride of a row-form tile, bf16 (16 pad bytes)
-    static constexpr int TLD = 40;                           // LDS row stride of a T-form tile, bf16 (64 data + 16 pad bytes)
+    // head dimension 256: tiles go global -> LDS directly (global_load_lds_dwordx4), so the images are unpadded; row-form
+    // rows (512 B) keep their 16-byte chunks XOR-swizzled by the row, T-form rows (64 B) are conflict-free as they stand
+    static constexpr bool kDma = HD == 256;
+    static constexpr int RLD = kDma ? HD : HD + 8;           // LDS row stride of a row-form tile, bf16 (16 pad bytes)
+    static constexpr int TLD = kDma ? 32 : 40;               // LDS row stride of a T-form tile, bf16 (64 data [+ 16 pad] bytes)
     static constexpr int RTILE = BN * RLD;                   // bf16 elements of one row-form tile
     static constexpr int TTILE = NG * HD * TLD;              // ... of one T-form tile
 };
@@ -485,24 +488,53 @@ __device__ __forceinline__ void b3_commit_t(__bf16* tile, const uint4 (&v)[B3Sta
         *reinterpret_cast<uint4*>(tile + (idx >> 2) * C::TLD + (idx & 3) * 8) = v[i];
     }
 }
-// the two steps in one (no prefetch)
+// the two steps in one (no prefetch); at head dimension 256 as LDS-DMA: no staging registers, every piece of every tile of a
+// step in flight at once (through registers the compiler, out of registers, waited for each 16-byte piece in turn: 24 round
+// trips per step).  The caller waits (b3_dma_wait) before its barrier; the compiler does not count these loads.
+__device__ __forceinline__ void b3_dma(const void* src_base /* uniform */, unsigned byte_off, void* lds_dst /* uniform */) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(byte_off), "s"(src_base), "s"(dst) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ void b3_dma_wait() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+}
 template <int HD>
 __device__ __forceinline__ void b3_load_rows(__bf16* tile, const __bf16* __restrict__ src) {
     using C = B3Cfg<HD>;
     constexpr int V8 = HD / 8;
+    if constexpr (C::kDma) {
+        // BN rows of 512 B = BN / 2 KiB; wave w issues KiB q = w, w + 4, ..: rows 2q, 2q + 1, chunk = slot ^ (row & 31)
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-    for (int idx = threadIdx.x; idx < C::BN * V8; idx += 64 * kSaWaves) {
-        const uint4 v = reinterpret_cast<const uint4*>(src)[idx];
-        *reinterpret_cast<uint4*>(tile + (idx / V8) * C::RLD + (idx % V8) * 8) = v;
+        for (int q = wave; q < C::BN / 2; q += kSaWaves) {
+            const int r = 2 * q + (lane >> 5), c = (lane & 31) ^ (r & 31);
+            b3_dma(src, (unsigned)(r * (HD * 2) + c * 16), reinterpret_cast<char*>(tile) + q * 1024);
+        }
+    } else {
+#pragma unroll
+        for (int idx = threadIdx.x; idx < C::BN * V8; idx += 64 * kSaWaves) {
+            const uint4 v = reinterpret_cast<const uint4*>(src)[idx];
+            *reinterpret_cast<uint4*>(tile + (idx / V8) * C::RLD + (idx % V8) * 8) = v;
+        }
     }
 }
 template <int HD>
 __device__ __forceinline__ void b3_load_t(__bf16* tile, const __bf16* __restrict__ src) {
     using C = B3Cfg<HD>;
+    if constexpr (C::kDma) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-    for (int idx = threadIdx.x; idx < C::NG * HD * 4; idx += 64 * kSaWaves) {
-        const uint4 v = reinterpret_cast<const uint4*>(src)[idx];
-        *reinterpret_cast<uint4*>(tile + (idx >> 2) * C::TLD + (idx & 3) * 8) = v;
+        for (int q = wave; q < C::NG * HD * 64 / 1024; q += kSaWaves)
+            b3_dma(src, (unsigned)(q * 1024 + lane * 16), reinterpret_cast<char*>(tile) + q * 1024);
+    } else {
+#pragma unroll
+        for (int idx = threadIdx.x; idx < C::NG * HD * 4; idx += 64 * kSaWaves) {
+            const uint4 v = reinterpret_cast<const uint4*>(src)[idx];
+            *reinterpret_cast<uint4*>(tile + (idx >> 2) * C::TLD + (idx & 3) * 8) = v;
+        }
     }
 }
 // score product of tile t of a row-form tile with a wave's own rows (B operand in registers)
@@ -511,10 +543,19 @@ __device__ __forceinline__ f32x4 b3_dot(const __bf16* th, const __bf16* tl, int 
                                         int j, int kk) {
     using C = B3Cfg<HD>;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int at = (16 * t + j) * C::RLD + 8 * kk;
+    if constexpr (C::kDma) {
+        const int row = 16 * t + j;
 #pragma unroll
-    for (int k = 0; k < C::KS; ++k)
-        acc = mma3(*reinterpret_cast<const bf16x8*>(th + at + 32 * k), *reinterpret_cast<const bf16x8*>(tl + at + 32 * k), bh[k], bl[k], acc);
+        for (int k = 0; k < C::KS; ++k) {
+            const int at = row * C::RLD + (((4 * k + kk) ^ (row & 31)) << 3);          // chunk 4 k + kk of the row, swizzled
+            acc = mma3(*reinterpret_cast<const bf16x8*>(th + at), *reinterpret_cast<const bf16x8*>(tl + at), bh[k], bl[k], acc);
+        }
+    } else {
+        const int at = (16 * t + j) * C::RLD + 8 * kk;
+#pragma unroll
+        for (int k = 0; k < C::KS; ++k)
+            acc = mma3(*reinterpret_cast<const bf16x8*>(th + at + 32 * k), *reinterpret_cast<const bf16x8*>(tl + at + 32 * k), bh[k], bl[k], acc);
+    }
     return acc;
 }
 // second product: acc[ct] += T-form tile (group g, column 16 ct + j) . (wh, wl)
@@ -629,7 +670,7 @@ __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, float* __restrict__ lse2, int M, int Mp, int d, float scale,
                           float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch) {
     using C = B3Cfg<HD>;
-    __shared__ __attribute__((aligned(16))) __bf16 sm[2 * C::RTILE + 2 * C::TTILE];
+    __shared__ __attribute__((aligned(1024))) __bf16 sm[2 * C::RTILE + 2 * C::TTILE];
     __bf16 *kh = sm, *kl = sm + C::RTILE, *vh = sm + 2 * C::RTILE, *vl = vh + C::TTILE;
     const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
     const size_t head = (size_t)seq * H + h, hoff = head * Mp * HD;
@@ -666,6 +707,7 @@ void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, f
             b3_load_rows<HD>(kl, K.rl + hoff + (size_t)n0 * HD);
             b3_load_t<HD>(vh, V.th + hoff + (size_t)n0 * HD);
             b3_load_t<HD>(vl, V.tl + hoff + (size_t)n0 * HD);
+            if (C::kDma) b3_dma_wait();
         }
         __syncthreads();
         f32x4 s[C::NT];
@@ -722,7 +764,7 @@ template <int HD>
 __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_b3_map_kernel(B3Form Q, B3Form K, const float* __restrict__ lse2, float* __restrict__ map, int M, int Mp, float scale) {
     using C = B3Cfg<HD>;
-    __shared__ __attribute__((aligned(16))) __bf16 sm[2 * C::RTILE];
+    __shared__ __attribute__((aligned(1024))) __bf16 sm[2 * C::RTILE];
     __bf16 *kh = sm, *kl = sm + C::RTILE;
     const int seq = blockIdx.z;
     const size_t hoff = (size_t)seq * Mp * HD;
@@ -754,6 +796,7 @@ void bag_sa_b3_map_kernel(B3Form Q, B3Form K, const float* __restrict__ lse2, fl
         } else {
             b3_load_rows<HD>(kh, K.rh + hoff + (size_t)n0 * HD);
             b3_load_rows<HD>(kl, K.rl + hoff + (size_t)n0 * HD);
+            if (C::kDma) b3_dma_wait();
         }
         __syncthreads();
 #pragma unroll
@@ -781,7 +824,7 @@ void bag_sa_b3_dq_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* _
                          const float* __restrict__ lse2, float* __restrict__ dqkv, float* __restrict__ delta, int M, int Mp, int d,
                          float scale, float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch) {
     using C = B3Cfg<HD>;
-    __shared__ __attribute__((aligned(16))) __bf16 sm[4 * C::RTILE + 2 * C::TTILE];
+    __shared__ __attribute__((aligned(1024))) __bf16 sm[4 * C::RTILE + 2 * C::TTILE];
     __bf16 *kh = sm, *kl = sm + C::RTILE, *vh = sm + 2 * C::RTILE, *vl = sm + 3 * C::RTILE, *kth = sm + 4 * C::RTILE, *ktl = kth + C::TTILE;
     const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
     const size_t head = (size_t)seq * H + h, hoff = head * Mp * HD;
@@ -841,6 +884,7 @@ void bag_sa_b3_dq_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* _
             b3_load_rows<HD>(vl, V.rl + hoff + (size_t)n0 * HD);
             b3_load_t<HD>(kth, K.th + hoff + (size_t)n0 * HD);
             b3_load_t<HD>(ktl, K.tl + hoff + (size_t)n0 * HD);
+            if (C::kDma) b3_dma_wait();
         }
         __syncthreads();
         uint32_t w[C::NT];
@@ -884,7 +928,7 @@ void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* 
                           float* __restrict__ dqkv, int M, int Mp, int d, float scale, float drop_p, unsigned long long seed,
                           unsigned long long offset, const unsigned long long* epoch) {
     using C = B3Cfg<HD>;
-    __shared__ __attribute__((aligned(16))) __bf16 sm[4 * C::RTILE + 4 * C::TTILE];
+    __shared__ __attribute__((aligned(1024))) __bf16 sm[4 * C::RTILE + 4 * C::TTILE];
     __shared__ __attribute__((aligned(16))) float st[2 * C::BN];
     __bf16 *qh = sm, *ql = sm + C::RTILE, *gh = sm + 2 * C::RTILE, *gl = sm + 3 * C::RTILE;
     __bf16 *qth = sm + 4 * C::RTILE, *qtl = qth + C::TTILE, *gth = qth + 2 * C::TTILE, *gtl = qth + 3 * C::TTILE;
@@ -938,6 +982,7 @@ void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* 
             b3_load_t<HD>(qtl, Q.tl + hoff + (size_t)q0 * HD);
             b3_load_t<HD>(gth, DO.th + hoff + (size_t)q0 * HD);
             b3_load_t<HD>(gtl, DO.tl + hoff + (size_t)q0 * HD);
+            if (C::kDma) b3_dma_wait();
         }
         if (threadIdx.x < C::BN) {
             const int qq = q0 + threadIdx.x;
