@@ -394,16 +394,20 @@ def ge_extra(dev, patches=15000, steps=5):
             b_.record()
     torch.cuda.synchronize(dev)
     us = [a_.elapsed_time(b_) * 1e3 for a_, b_ in ev[1:]]
-    flops = 2 * 2.0 * patches * patches * d                       # scores + context, all heads
+    flops = 2 * 2.0 * patches * patches * d                       # scores + context, all heads (algorithmic)
     avg = sum(us) / len(us)
     del model, wsi, qkv
+    # the kernel runs each product as three bf16 MFMA terms (hi*hi + lo*hi + hi*lo): issued matrix flops = 3 x algorithmic,
+    # priced against the dense bf16 peak; the rest of its time is the soft-max / dropout / operand-split VALU work
     return {"metric": "slides/sec (fwd+bwd) at 15k-patch bags", "value": round(1e3 / ms, 2), "unit": "slides/s", "n_gpus": 1,
-            "steps": steps, "ms_per_step": round(ms, 2), "dtype": "f32 attention / bf16 bag", "data": "synthetic",
+            "steps": steps, "ms_per_step": round(ms, 2), "dtype": "bf16x3 attention (hi+lo operands, fp32 accumulate) / bf16 bag",
+            "data": "synthetic",
             "config": {"workload": f"GE-NACAGAT medium fwd+CE+bwd, one {patches}x1024 bf16 bag per step, M x M map returned",
                        "launch": "eager"},
-            "roofline": {"bound": "mfma", "kernel": "bag_sa_fwd_kernel<32> (8 heads, dropout 0.25, fp32 MFMA)",
-                         "achieved": round(flops / avg / 1e6, 2), "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": round(flops / avg / 1e6 / 157.3, 4), "traffic": None, "flops_per_launch": flops,
+            "roofline": {"bound": "mfma", "kernel": "bag_sa_b3_fwd_kernel<32> (8 heads, dropout 0.25, three-term bf16 MFMA)",
+                         "achieved": round(3 * flops / avg / 1e6, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(3 * flops / avg / 1e6 / 2500.0, 4), "traffic": None, "flops_per_launch": 3 * flops,
+                         "algorithmic_flops_per_launch": flops, "algorithmic_tflops": round(flops / avg / 1e6, 2),
                          "avg_launch_us": round(avg, 1), "min_launch_us": round(min(us), 1), "launches_timed": len(us)}}
 
 

@@ -4,6 +4,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adam_flat" in r["Kernel_Name"]]
 step = rows[idx[-2] + 1: idx[-1] + 1]
+# the captured step begins with its counter bump; anything between the previous Adam and that (bench.py's timed roofline
+# launch) is not part of it
+starts = [i for i, r in enumerate(step) if "counters_bump" in r["Kernel_Name"]]
+if starts:
+    step = step[starts[-1]:]
 t0 = int(step[0]["Start_Timestamp"])
 print("step span us", (int(step[-1]["End_Timestamp"]) - t0) / 1e3, "kernels", len(step),
       "sum us", sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step) / 1e3)
