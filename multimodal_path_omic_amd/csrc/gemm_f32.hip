@@ -28,6 +28,7 @@ void mpo_direct_group_nb4(const GemmGroup& grp, dim3 grid, hipStream_t stream);
 void mpo_direct_group_nb8(const GemmGroup& grp, dim3 grid, hipStream_t stream);
 void mpo_fast_group(const GemmGroup& grp, int gate_classes, int nbmax, dim3 grid, hipStream_t stream);
 void mpo_fast_single(const GemmArgs& g, int layout, int gate_classes, int nbmax, dim3 grid, hipStream_t stream);
+void mpo_rows_single(const GemmArgs& g, int layout, int gate_class, hipStream_t stream);
 namespace {
 inline int direct_nbmax(int k) { return k <= 256 ? 4 : DMAXB; }
 // A product the branch-free body (gemm_f32_fast.h) can run: whole tiles, whole k-blocks per wave, vector-loadable
@@ -49,13 +50,45 @@ inline int fast_class(const GemmArgs& g) {
         default: return -1;
     }
 }
+// -> gate class, or -1: a product with many rows for gemm_f32_rows.hip (32 x 64 tiles): A k-contiguous, whole column blocks
+// and k-blocks, vector-loadable operands, no bias-gradient output
+inline int rows_class(const GemmArgs& g, int layout) {
+    if (!g_fast_path || !(layout & 2) || g.M < 512 || (g.N & 63) || g.K < 64 || (g.K & 63) || g.bias_grad != nullptr) return -1;
+    if ((g.lda & 3) || !aligned16(g.A)) return -1;
+    if ((layout & 1) && ((g.ldb & 3) || !aligned16(g.B))) return -1;
+    switch (g.gate_mode) {
+        case MPO_GATE_NONE: return 0;
+        case MPO_GATE_RNG: return 2;
+        case MPO_GATE_RELU: case MPO_GATE_ELU: case MPO_GATE_TANH: case MPO_GATE_SIGMOID: case MPO_GATE_MUL:
+            return (g.gate != nullptr && aligned16(g.gate)) ? 1 : -1;
+        case MPO_GATE_ELU_ADROP: return (g.gate != nullptr && aligned16(g.gate)) ? 3 : -1;
+        default: return -1;
+    }
+}
 void launch_direct_single(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream) {
+    const int rc = rows_class(g, layout);
+    if (rc >= 0) { mpo_rows_single(g, layout, rc, stream); return; }
     const int fc = fast_class(g);
     if (fc >= 0) { mpo_fast_single(g, layout, fc, direct_nbmax(g.K), grid, stream); return; }
     if (direct_nbmax(g.K) == 4) mpo_direct_single_nb4(g, layout, grid, stream);
     else mpo_direct_single_nb8(g, layout, grid, stream);
 }
-void launch_direct_group(const GemmGroup& grp, dim3 grid, hipStream_t stream) {
+void launch_direct_group(const GemmGroup& all, dim3 grid, hipStream_t stream) {
+    // members with many rows leave the group for their own launches (gemm_f32_rows.hip); the members of a group are
+    // independent products, so the order of the launches does not matter
+    GemmGroup grp;
+    grp.n = 0;
+    for (int i = 0; i < all.n; ++i) {
+        const int rc = rows_class(all.g[i], all.g[i].layout);
+        if (rc >= 0) mpo_rows_single(all.g[i], all.g[i].layout, rc, stream);
+        else grp.g[grp.n++] = all.g[i];
+    }
+    if (grp.n == 0) return;
+    if (grp.n != all.n) {
+        int mx = 0, nx = 0;
+        for (int i = 0; i < grp.n; ++i) { mx = std::max(mx, grp.g[i].M); nx = std::max(nx, grp.g[i].N); }
+        grid = dim3((nx + DB - 1) / DB, (mx + DB - 1) / DB, grp.n);
+    }
     int kmax = 0, classes = 0;                                    // classes: bit c set when a member has gate class c
     bool fast = true;
     for (int i = 0; i < grp.n; ++i) {

@@ -418,3 +418,23 @@ def test_model_with_other_fusion_matches_oracle(dev, fusion):
         ref = p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])
         scale = max(float(ref.abs().max()), 1e-4)
         assert float((prm.grad.cpu() - ref).abs().max()) / scale < (1e-2 if n.startswith("H.") else 2e-3), n
+
+
+@pytest.mark.parametrize("rows,k,n,act", [(1500, 256, 768, "none"), (515, 512, 256, "relu"), (2049, 192, 64, "tanh"), (1024, 64, 512, "sigmoid")])
+def test_many_row_products_equal_torch(dev, rows, k, n, act):
+    """Products with >= 512 rows (the gene-expression model's set-Transformer / pooling over the rows of a bag) run on 32 x 64
+    tiles (csrc/gemm_f32_rows.hip): forward and the input gradient, ragged row counts, against torch."""
+    g = syn.rng(9100 + rows)
+    x, w, b, probe = syn.normal(g, (rows, k)), syn.normal(g, (n, k)) * 0.1, syn.normal(g, (n,)), syn.normal(g, (rows, n))
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, act)
+    (y * probe.to(dev)).sum().backward()
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr = {"none": lambda t: t, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act](yr)
+    (yr * probe.double()).sum().backward()
+
+    def rel(a, r):
+        return float((a.detach().double().cpu() - r).abs().max() / r.abs().max())
+    assert rel(y, yr) < 1e-5
+    assert rel(xd.grad, xr.grad) < 1e-5 and rel(wd.grad, wr.grad) < 1e-4 and rel(bd.grad, br.grad) < 1e-4
