@@ -29,6 +29,7 @@ void mpo_direct_group_nb8(const GemmGroup& grp, dim3 grid, hipStream_t stream);
 void mpo_fast_group(const GemmGroup& grp, int gate_classes, int nbmax, dim3 grid, hipStream_t stream);
 void mpo_fast_single(const GemmArgs& g, int layout, int gate_classes, int nbmax, dim3 grid, hipStream_t stream);
 void mpo_rows_single(const GemmArgs& g, int layout, int gate_class, hipStream_t stream);
+int mpo_longk_single(const GemmArgs& g, int gate_class, hipStream_t stream);
 namespace {
 inline int direct_nbmax(int k) { return k <= 256 ? 4 : DMAXB; }
 // A product the branch-free body (gemm_f32_fast.h) can run: whole tiles, whole k-blocks per wave, vector-loadable
@@ -65,22 +66,42 @@ inline int rows_class(const GemmArgs& g, int layout) {
         default: return -1;
     }
 }
+// -> gate class, or -1: a weight-gradient product over a long row axis for gemm_f32_longk.hip (K cut into slices over the grid,
+// partial blocks added atomically): both operands k-strided, whole 32 x 64 blocks, nothing but alpha in the epilogue
+inline int longk_class(const GemmArgs& g, int layout) {
+    if (!g_fast_path || layout != 0 || g.K < 2048 || (g.M & 31) || (g.N & 63) || (g.lda & 3)) return -1;
+    if (g.bias || g.mask || g.residual || g.act != MPO_ACT_NONE || g.drop_p > 0.f) return -1;
+    switch (g.gate_mode) {
+        case MPO_GATE_NONE: return 0;
+        case MPO_GATE_RNG: return 2;
+        case MPO_GATE_RELU: case MPO_GATE_ELU: case MPO_GATE_TANH: case MPO_GATE_SIGMOID: case MPO_GATE_MUL:
+            return g.gate != nullptr ? 1 : -1;
+        case MPO_GATE_ELU_ADROP: return g.gate != nullptr ? 3 : -1;
+        default: return -1;
+    }
+}
+inline void launch_longk(const GemmArgs& g, int gate_class, hipStream_t stream) {
+    if (int e = mpo_longk_single(g, gate_class, stream)) mpo_set_error("long-K weight gradient: zero-fill failed (hip error %d)", e);
+}
 void launch_direct_single(const GemmArgs& g, int layout, dim3 grid, hipStream_t stream) {
     const int rc = rows_class(g, layout);
     if (rc >= 0) { mpo_rows_single(g, layout, rc, stream); return; }
+    const int lc = longk_class(g, layout);
+    if (lc >= 0) { launch_longk(g, lc, stream); return; }
     const int fc = fast_class(g);
     if (fc >= 0) { mpo_fast_single(g, layout, fc, direct_nbmax(g.K), grid, stream); return; }
     if (direct_nbmax(g.K) == 4) mpo_direct_single_nb4(g, layout, grid, stream);
     else mpo_direct_single_nb8(g, layout, grid, stream);
 }
 void launch_direct_group(const GemmGroup& all, dim3 grid, hipStream_t stream) {
-    // members with many rows leave the group for their own launches (gemm_f32_rows.hip); the members of a group are
-    // independent products, so the order of the launches does not matter
+    // members with many rows (gemm_f32_rows.hip) or a long inner dimension (gemm_f32_longk.hip) leave the group for their own
+    // launches; the members of a group are independent products, so the order of the launches does not matter
     GemmGroup grp;
     grp.n = 0;
     for (int i = 0; i < all.n; ++i) {
-        const int rc = rows_class(all.g[i], all.g[i].layout);
+        const int rc = rows_class(all.g[i], all.g[i].layout), lc = longk_class(all.g[i], all.g[i].layout);
         if (rc >= 0) mpo_rows_single(all.g[i], all.g[i].layout, rc, stream);
+        else if (lc >= 0) launch_longk(all.g[i], lc, stream);
         else grp.g[grp.n++] = all.g[i];
     }
     if (grp.n == 0) return;

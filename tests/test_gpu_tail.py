@@ -420,10 +420,12 @@ def test_model_with_other_fusion_matches_oracle(dev, fusion):
         assert float((prm.grad.cpu() - ref).abs().max()) / scale < (1e-2 if n.startswith("H.") else 2e-3), n
 
 
-@pytest.mark.parametrize("rows,k,n,act", [(1500, 256, 768, "none"), (515, 512, 256, "relu"), (2049, 192, 64, "tanh"), (1024, 64, 512, "sigmoid")])
+@pytest.mark.parametrize("rows,k,n,act", [(1500, 256, 768, "none"), (515, 512, 256, "relu"), (2049, 192, 64, "tanh"), (1024, 64, 512, "sigmoid"),
+                                          (4100, 256, 512, "relu"), (15000, 512, 256, "none")])
 def test_many_row_products_equal_torch(dev, rows, k, n, act):
     """Products with >= 512 rows (the gene-expression model's set-Transformer / pooling over the rows of a bag) run on 32 x 64
-    tiles (csrc/gemm_f32_rows.hip): forward and the input gradient, ragged row counts, against torch."""
+    tiles (csrc/gemm_f32_rows.hip): forward and the input gradient, ragged row counts; from 2 048 rows the weight and bias
+    gradients run with the row axis cut over the grid (csrc/gemm_f32_longk.hip).  Against torch."""
     g = syn.rng(9100 + rows)
     x, w, b, probe = syn.normal(g, (rows, k)), syn.normal(g, (n, k)) * 0.1, syn.normal(g, (n,)), syn.normal(g, (rows, n))
     xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
