@@ -46,7 +46,11 @@ def test_headline_kernels_are_register_resident(usage):
     """The kernels the bench line is made of (E=256, bf16 bag) must have no scratch and no spills at all."""
     hot = ["coattn_fwd_partial_kernelILi256ELb0", "coattn_bwd_kernelILi256ELb0", "bag_rowdot_gated_exact_kernelILi256E", "patch_coattn_fwd_kernel", "patch_wgrad_kernel",
            "bag_colacc_gated_kernelILi256ELb1", "bag_outer_gated_kernelILi256ELb1", "gemm_f32_direct_kernelILi4",
-           "gemm_f32_direct_kernelILi8"]
+           "gemm_f32_direct_kernelILi8",
+           # row f3: the three-term bf16 self-attention kernels of the medium model and the many-row GEMM forms
+           "bag_sa_b3_fwd_kernelILi32E", "bag_sa_b3_dq_kernelILi32E", "bag_sa_b3_dkv_kernelILi32E", "bag_sa_b3_fwd_kernelILi256E",
+           "bag_sa_b3_dq_kernelILi256E", "bag_sa_b3_dkv_kernelILi256E", "bag_sa_b3_map_kernelILi256E", "gemm_f32_rows_kernel",
+           "gemm_f32_longk_kernel"]
     for h in hot:
         match = [v for k, v in usage.items() if h in k]
         assert match, f"kernel {h} not found in the build"
@@ -54,14 +58,16 @@ def test_headline_kernels_are_register_resident(usage):
             assert v["scratch_bytes"] == 0 and v["vgpr_spill"] == 0, (h, v)
 
 
-def test_m0_is_only_touched_by_the_direct_to_lds_loads(tmp_path):
-    """K1 forward issues its tile loads from inline asm that sets M0 (the LDS destination of global_load_lds_dwordx4)
-    and lists it as clobbered, which the compiler only honours as long as it has no use of M0 of its own in that kernel.
-    Compile the file to assembly and check that every M0 access sits inside one of those asm blocks."""
+@pytest.mark.parametrize("source", ["coattn_fwd.hip", "bag_selfattn.hip"])
+def test_m0_is_only_touched_by_the_direct_to_lds_loads(tmp_path, source):
+    """K1 forward (and the head-dimension-256 bag self-attention kernels) issue their tile loads from inline asm that sets
+    M0 (the LDS destination of global_load_lds_dwordx4) and lists it as clobbered, which the compiler only honours as long
+    as it has no use of M0 of its own in that kernel.  Compile the file to assembly and check that every M0 access sits
+    inside one of those asm blocks."""
     import os
     import subprocess
-    src = os.path.join(_build.CSRC, "coattn_fwd.hip")
-    out = tmp_path / "coattn_fwd.s"
+    src = os.path.join(_build.CSRC, source)
+    out = tmp_path / (source + ".s")
     flags = [f for f in _build.FLAGS if not f.startswith("-Rpass")]
     subprocess.run(["hipcc", *flags, "-S", "--cuda-device-only", src, "-o", str(out)], check=True, capture_output=True)
     in_asm, inside, outside = False, 0, []
