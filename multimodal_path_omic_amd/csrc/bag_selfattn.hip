@@ -62,9 +62,16 @@ __device__ __forceinline__ SaDrop sa_drop(float p, unsigned long long seed, unsi
     return d;
 }
 // the 16 bytes of block (q / 4, key / 4); element (q % 4, key % 4) is byte 4 * (q % 4) + key % 4
+__device__ __forceinline__ uint32_t sa_block_x(const SaDrop& d, int qb, int kb) {
+    return (d.key ^ ((uint32_t)qb * 0x9E3779B1u)) + (uint32_t)kb * 0x85EBCA77u;
+}
+// word i (= q % 4) of the block alone: what the forward / dQ orientation needs (one query per lane)
+__device__ __forceinline__ uint32_t sa_block_word(const SaDrop& d, int qb, int kb, int i) {
+    return sa_fmix(sa_block_x(d, qb, kb) + (uint32_t)i * 0x27D4EB2Fu);
+}
 __device__ __forceinline__ uint4 sa_block(const SaDrop& d, int qb, int kb) {
-    const uint32_t x = (d.key ^ ((uint32_t)qb * 0x9E3779B1u)) + (uint32_t)kb * 0x85EBCA77u;
-    return make_uint4(sa_fmix(x), sa_fmix(x + 0x27D4EB2Fu), sa_fmix(x + 0x4FA9D65Eu), sa_fmix(x + 0x777EC18Du));
+    const uint32_t x = sa_block_x(d, qb, kb);
+    return make_uint4(sa_fmix(x), sa_fmix(x + 0x27D4EB2Fu), sa_fmix(x + 2u * 0x27D4EB2Fu), sa_fmix(x + 3u * 0x27D4EB2Fu));
 }
 __device__ __forceinline__ float sa_keep(const SaDrop& d, uint32_t word, int byte) {
     return ((word >> (8 * byte)) & 255u) >= d.thr ? d.inv_keep : 0.f;
@@ -179,8 +186,7 @@ void bag_sa_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, flo
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s[t][r] = fast_exp2(s[t][r] - mx); l += s[t][r]; }
             if (dr.thr) {
-                const uint4 blk = sa_block(dr, q >> 2, (n0 + 16 * t + 4 * kk) >> 2);
-                const uint32_t w = sa_word(blk, q & 3);
+                const uint32_t w = sa_block_word(dr, q >> 2, (n0 + 16 * t + 4 * kk) >> 2, q & 3);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[t][r] *= sa_keep(dr, w, r);
             }
@@ -290,8 +296,7 @@ void bag_sa_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict
             f32x4 s = sa_tile_dot<HD>(kt, t, qf, j, kk);
             f32x4 dp = sa_tile_dot<HD>(vt, t, dof, j, kk);
             if (dr.thr) {
-                const uint4 blk = sa_block(dr, q >> 2, (n0 + 16 * t + 4 * kk) >> 2);
-                const uint32_t w = sa_word(blk, q & 3);
+                const uint32_t w = sa_block_word(dr, q >> 2, (n0 + 16 * t + 4 * kk) >> 2, q & 3);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dp[r] *= sa_keep(dr, w, r);
             }
@@ -558,15 +563,23 @@ __device__ __forceinline__ f32x4 b3_dot(const __bf16* th, const __bf16* tl, int 
     }
     return acc;
 }
-// second product: acc[ct] += T-form tile (group g, column 16 ct + j) . (wh, wl)
+// second product: acc[ct] += T-form tile (group g, column 16 ct + j) . (wh, wl); two column tiles at a time with the three
+// terms interleaved, so that consecutive MFMAs do not wait for each other's accumulator
 template <int HD>
 __device__ __forceinline__ void b3_tacc(f32x4 (&acc)[HD / 16], const __bf16* th, const __bf16* tl, int g, const bf16x8& wh, const bf16x8& wl,
                                         int j, int kk) {
     using C = B3Cfg<HD>;
 #pragma unroll
-    for (int ct = 0; ct < C::CT; ++ct) {
-        const int at = (g * HD + 16 * ct + j) * C::TLD + 8 * kk;
-        acc[ct] = mma3(*reinterpret_cast<const bf16x8*>(th + at), *reinterpret_cast<const bf16x8*>(tl + at), wh, wl, acc[ct]);
+    for (int ct = 0; ct < C::CT; ct += 2) {
+        const int at0 = (g * HD + 16 * ct + j) * C::TLD + 8 * kk, at1 = at0 + 16 * C::TLD;
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(th + at0), ah1 = *reinterpret_cast<const bf16x8*>(th + at1);
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(tl + at0), al1 = *reinterpret_cast<const bf16x8*>(tl + at1);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, wh, acc[ct], 0, 0, 0);
+        acc[ct + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, wh, acc[ct + 1], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, wh, acc[ct], 0, 0, 0);
+        acc[ct + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, wh, acc[ct + 1], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, wl, acc[ct], 0, 0, 0);
+        acc[ct + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, wl, acc[ct + 1], 0, 0, 0);
     }
 }
 template <int HD>
@@ -586,24 +599,13 @@ __device__ __forceinline__ void b3_split8(const f32x4& a, const f32x4& b, bf16x8
         split_bf16(b[e], h, l); hi[4 + e] = h; lo[4 + e] = l;
     }
 }
-__device__ __forceinline__ uint32_t pick4(const uint32_t (&v)[4], int i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
-// forward / dQ orientation (lane column = query q, NT key tiles): w[t] = word (q % 4) of the block of (q / 4, tile t's keys).
-// With four tiles per step the four lanes of a quad (same q / 4) each draw ONE tile's block and exchange words.
+// forward / dQ orientation (lane column = query q, NT key tiles): w[t] = word (q % 4) of the block of (q / 4, tile t's keys) --
+// the one word of each block this lane's query uses, hashed directly (two multiplies per tile; no exchange between lanes)
 template <int NT>
 __device__ __forceinline__ void b3_words_q(const SaDrop& dr, int q, int n0, int kk, int lane, uint32_t (&w)[NT]) {
-    if constexpr (NT == 4) {
-        const int lq = lane & 3;
-        const uint4 b = sa_block(dr, q >> 2, (n0 + 16 * lq + 4 * kk) >> 2);
-        const uint32_t own[4] = {b.x, b.y, b.z, b.w};
-        uint32_t got[4];
+    (void)lane;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) got[x] = (uint32_t)__shfl_xor((int)pick4(own, lq ^ x), x);     // = word lq of tile (lq ^ x)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) w[t] = pick4(got, t ^ lq);
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) w[t] = sa_word(sa_block(dr, q >> 2, (n0 + 16 * t + 4 * kk) >> 2), q & 3);
-    }
+    for (int t = 0; t < NT; ++t) w[t] = sa_block_word(dr, q >> 2, (n0 + 16 * t + 4 * kk) >> 2, q & 3);
 }
 // dK/dV orientation (lane column = key, NT query tiles, all four words of a block used by every lane of the quad)
 template <int NT>
