@@ -613,12 +613,13 @@ __device__ __forceinline__ void b3_blocks_key(const SaDrop& dr, int key, int q0,
     if constexpr (NT == 4) {
         const int lq = lane & 3;
         const uint4 b = sa_block(dr, (q0 + 16 * lq + 4 * kk) >> 2, key >> 2);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int from = (lane & ~3) | t;
-            w[t][0] = (uint32_t)__shfl((int)b.x, from); w[t][1] = (uint32_t)__shfl((int)b.y, from);
-            w[t][2] = (uint32_t)__shfl((int)b.z, from); w[t][3] = (uint32_t)__shfl((int)b.w, from);
-        }
+        // quad broadcasts as DPP moves (quad_perm [t, t, t, t]): one vector instruction each, no LDS round trip
+#define MPO_QUAD_BCAST(v, t) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (t) * 0x55, 0xF, 0xF, false)
+        w[0][0] = MPO_QUAD_BCAST(b.x, 0); w[0][1] = MPO_QUAD_BCAST(b.y, 0); w[0][2] = MPO_QUAD_BCAST(b.z, 0); w[0][3] = MPO_QUAD_BCAST(b.w, 0);
+        w[1][0] = MPO_QUAD_BCAST(b.x, 1); w[1][1] = MPO_QUAD_BCAST(b.y, 1); w[1][2] = MPO_QUAD_BCAST(b.z, 1); w[1][3] = MPO_QUAD_BCAST(b.w, 1);
+        w[2][0] = MPO_QUAD_BCAST(b.x, 2); w[2][1] = MPO_QUAD_BCAST(b.y, 2); w[2][2] = MPO_QUAD_BCAST(b.z, 2); w[2][3] = MPO_QUAD_BCAST(b.w, 2);
+        w[3][0] = MPO_QUAD_BCAST(b.x, 3); w[3][1] = MPO_QUAD_BCAST(b.y, 3); w[3][2] = MPO_QUAD_BCAST(b.z, 3); w[3][3] = MPO_QUAD_BCAST(b.w, 3);
+#undef MPO_QUAD_BCAST
     } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
