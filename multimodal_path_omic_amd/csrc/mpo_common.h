@@ -49,6 +49,23 @@ __device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c
     }
     return make_uint4(c0, c1, c2, c3);
 }
+// ---- counter hash for masks that only ONE kernel ever generates (the fused patch layer writes its mask into H_bag as zeros;
+// consumers read it back from there).  32-bit integer multiplies run at a quarter of the vector rate: Philox's 40 per draw were
+// 640 cycles per 16 elements in that kernel's epilogue; this is the murmur3 finaliser (full avalanche, 2 multiplies per word).
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t hash_stream_key(unsigned long long seed, unsigned long long offset) {      // once per kernel
+    uint32_t k = fmix32((uint32_t)seed ^ 0x5A17u);
+    k = fmix32(k ^ (uint32_t)(seed >> 32));
+    k = fmix32(k ^ (uint32_t)offset);
+    return fmix32(k ^ (uint32_t)(offset >> 32));
+}
+__device__ __forceinline__ uint4 hash4x32(uint32_t key, unsigned long long ctr) {
+    const uint32_t x = fmix32(key ^ (uint32_t)ctr) + (uint32_t)(ctr >> 32) * 0x85EBCA77u;
+    return make_uint4(fmix32(x + 0x27D4EB2Fu), fmix32(x + 2u * 0x27D4EB2Fu), fmix32(x + 3u * 0x27D4EB2Fu), fmix32(x + 4u * 0x27D4EB2Fu));
+}
 // keep-scale for element `idx` of a stream identified by (seed, stream): 0 or 1/(1-p)
 __device__ __forceinline__ float dropout_keep(uint64_t seed, uint64_t offset, uint64_t idx, float p, float inv_keep) {
     uint64_t ctr = offset + (idx >> 2);

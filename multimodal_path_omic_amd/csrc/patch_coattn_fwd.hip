@@ -15,7 +15,7 @@
 //     store of a row-major H image.  X fragments are read from an LDS ring; the W_H fragments of a lane are 16 contiguous
 //     bytes of global memory and come straight from L2 into registers one step ahead (512 KiB shared by every workgroup
 //     and re-read per block: sending it through LDS as well tripled the LDS-DMA traffic of a CU and made the loaders the
-//     bottleneck -- measured).  Epilogue per block: + bias, ReLU, Philox dropout, bf16, into the H image.
+//     bottleneck -- measured).  Epilogue per block: + bias, ReLU, dropout (counter hash), bf16, into the H image.
 //     During the even steps a GEMM wave also copies two rows of the PREVIOUS block's image out to H_bag (the backward pass
 //     reads it): the store tail of a block is issue-bound (~5 k cycles per 64 KiB), so it is spread under the next
 //     block's main loop instead of standing between two blocks.
@@ -236,6 +236,7 @@ void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the plain loads above must not sit in front of the ring)
     const unsigned long long offset = epoch_offset(offset_, epoch);
+    const uint32_t drop_key = hash_stream_key(seed, offset);          // (the stream offset is in the key: the counter below is the element group alone)
     const size_t pbase = wg.part;
     // Barrier sequence of EVERY role: 1 (prologue) + per block [16 step barriers + 1 image barrier] + 1 (states in LDS).
 
@@ -326,12 +327,12 @@ void patch_coattn_fwd_kernel(const __bf16* __restrict__ x,        // [total_rows
                 const float* lb = reinterpret_cast<const float*>(lds + OFF_BIAS) + 32 * wave + 4 * eg;
                 const f32x4 bv0 = *reinterpret_cast<const f32x4*>(lb), bv1 = *reinterpret_cast<const f32x4*>(lb + 16);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {                     // patch tiles 2 u, 2 u + 1 share one Philox draw: 16 elements, 8 bits each
+                for (int u = 0; u < 4; ++u) {                     // patch tiles 2 u, 2 u + 1 share one draw of the counter hash: 16 elements, 8 bits each
                     uint4 rnd = {0u, 0u, 0u, 0u};
                     if (drop_p > 0.f) {
-                        const unsigned long long ctr = offset + (unsigned long long)(row_begin + rb + 32 * u + (el & 15)) * 32ull
+                        const unsigned long long ctr = (unsigned long long)(row_begin + rb + 32 * u + (el & 15)) * 32ull
                                                        + (unsigned)(4 * wave + eg);
-                        rnd = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+                        rnd = hash4x32(drop_key, ctr);
                     }
                     const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
 #pragma unroll
