@@ -85,7 +85,7 @@ int mpo_coattn_mcat_forward(const void* bag, int bag_dtype, const int32_t* cu_ro
  * mpo_coattn_mcat_backward, which takes `saved` and h_bag exactly as after mpo_coattn_mcat_forward.
  *   patches [total_rows, patch_dim] bf16;  patch_weight [embed, patch_dim] fp32 (rounded to bf16 operands inside),
  *   patch_bias [embed] fp32.  Built for patch_dim 1024, embed 256 ('medium'), n_q <= 8.
- * Dropout: Philox (seed, offset [+ *rng_epoch << 40]), one draw per 16 elements, 8 random bits each: the realised drop
+ * Dropout: counter hash of (seed, offset [+ *rng_epoch << 40]), one draw per 16 elements, 8 random bits each: the realised drop
  * probability is round(256 p) / 256 (exact for the reference's 0.25) and the keep scale follows it; reserve
  * total_rows * embed / 16 + 1 counters. */
 size_t mpo_patch_coattn_workspace_bytes(int n_slides, int n_q, int embed, int patch_dim);
@@ -182,7 +182,7 @@ int mpo_step_counters_bump(uint64_t* rng_epoch, int32_t* adam_step, mpo_stream_t
  * k_dtype must be MPO_F32 even for a bf16 bag: the gate multiplies rounding errors of k (dS = (g+1) da),
  * so k is an intermediate that must not be stored in bf16 (hard part 4).
  *   score_maps  2 * n_q * total_rows floats (kept for backward);  attn_map  n_q * total_rows floats (output)
- *   seed/offset Philox counter of the attention-weight dropout; pass the same pair to backward.
+ *   seed/offset counter of the attention-weight dropout stream; pass the same pair to backward.
  * Backward takes gradients on all three returns (d_out, d_attn_map nullable, d_q_proj nullable) and emits
  * d_query, d_kbag (dk_dtype: a GRADIENT may be handed on in bf16), d_hbag (bag dtype) and the q / v / out-projection
  * gradients; the key slices of d_in_proj_* are zeroed (the caller back-propagates d_kbag through its GEMM).
@@ -239,7 +239,7 @@ int mpo_nacagat_patch_grad(const int32_t* cu_rows, int n_slides, int total_rows,
                            void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ==== the 6 x d token tail.  Parameter and gradient tensors are passed as arrays of device pointers in
- * the order listed per entry (the reference's state_dict order); dropout streams are Philox counters
+ * the order listed per entry (the reference's state_dict order); dropout streams are counters of a counter-based generator (masks = a pure function of seed and counter)
  * (seed, offset): pass the same pair to forward and backward, reserve *_rng_span() counters per call.
  * rng_epoch (nullable, device uint64): added x 2^40 to every stream offset inside the kernels, so a HIP graph
  * that froze (seed, offset) at capture still draws fresh masks on every replay once the host bumps *rng_epoch

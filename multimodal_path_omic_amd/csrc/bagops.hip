@@ -843,8 +843,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // The map kernels walk a (query, slide) row of the ragged map in ALIGNED GROUPS of four elements (absolute index
-// 4G .. 4G+3): one float4 access per array and ONE Philox draw per group (the dropout counter is index >> 2), with
-// the group's first/last elements masked at the row ends.  (Element-wise they drew one Philox per element: 53 / 106 us.)
+// 4G .. 4G+3): one float4 access per array and ONE draw per group (the dropout counter is index >> 2), with
+// the group's first/last elements masked at the row ends.  (Element-wise they drew once per element: 53 / 106 us.)
 struct MapRow {
     size_t base;       // absolute index of the row's first element
     int m_rows;
@@ -883,7 +883,7 @@ __device__ __forceinline__ void map_store4(float* __restrict__ p, size_t G, unsi
 // keep-scales of the four elements of group G (same draw as dropout_keep(seed, offset, 4G + j, ...))
 __device__ __forceinline__ f32x4 map_keep4(unsigned long long seed, unsigned long long offset, size_t G, float p, float inv_keep) {
     const unsigned long long ctr = offset + G;
-    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint4 r = draw4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
     f32x4 k;
 #pragma unroll

@@ -41,7 +41,7 @@ __device__ __forceinline__ void direct_gate(f32x4& v, const f32x4& gv, const Gat
         const size_t idx0 = (size_t)mn * ld + k0;
         if (gf.draws() && (idx0 & 3) == 0) {
             const uint64_t ctr = gf.off + (idx0 >> 2);
-            const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
+            const uint4 r = draw4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (k0 + j < k_lim) v[j] *= gf.with_word(gv[j], w[j]);
@@ -55,7 +55,7 @@ __device__ __forceinline__ void direct_gate(f32x4& v, const f32x4& gv, const Gat
     }
 }
 // Row-contiguous operand with a drawing gate: element (k0 + j, mn) has index (k0 + j) * ld + mn, so the four lanes of
-// a quad (mn = 4q .. 4q+3) share ONE Philox counter per j.  Lane s of the quad draws the counter of j = s and the
+// a quad (mn = 4q .. 4q+3) share ONE dropout counter per j.  Lane s of the quad draws the counter of j = s and the
 // quad transposes the 4 x 4 words with four quad shuffles: one draw per lane and fragment instead of four.
 // Every lane of the wave must call this (no early exit before the shuffles).
 __device__ __forceinline__ void direct_gate_rows_quad(f32x4& v, const f32x4& gv, const GateFn& gf, int ld, int mn, int mn_lim,
@@ -63,7 +63,7 @@ __device__ __forceinline__ void direct_gate_rows_quad(f32x4& v, const f32x4& gv,
     const int lq = lane & 3;
     const size_t idx_own = (size_t)(k0 + lq) * ld + (mn & ~3);           // first element of the quad's group for j = lq
     const uint64_t ctr = gf.off + (idx_own >> 2);
-    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
+    const uint4 r = draw4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
     const uint32_t own[4] = {r.x, r.y, r.z, r.w};
     uint32_t w[4];
 #pragma unroll
@@ -146,7 +146,7 @@ __device__ __forceinline__ void gemm_f32_direct_body(const GemmArgs& g, DirectLd
     const float e_mask = (e_in && g.mask) ? g.mask[eo] : 1.0f;
     const float e_res = (e_in && g.residual) ? g.residual[eo] : 0.f;
     const float e_old = (e_in && g.accumulate) ? g.C[eo] : 0.f;
-    // ... and the element's dropout draw (Philox, ~50 instructions) while those loads are in flight
+    // ... and the element's dropout draw (the counter hash) while those loads are in flight
     float e_keep = 1.0f;                                        // plain dropout: keep / (1 - p) or 0;  alpha dropout: 1 or 0
     if (g.drop_p > 0.f) {
         const unsigned long long doff = epoch_offset(g.drop_off, g.rng_epoch);

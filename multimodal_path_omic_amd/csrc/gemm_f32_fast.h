@@ -5,8 +5,8 @@
 // window step spent most of their 8-19 us walking that code (instruction fetch, not loads or MFMAs: weights hot in L2
 // made them 10 % faster, no more).  Nearly all of those products are regular:
 //     M % 16 == 0, N % 16 == 0, K % 16 == 0, leading dimensions % 4 == 0, 16-byte aligned operands,
-//     gate one of {none, a value gate (ReLU / ELU / tanh / sigmoid derivative, multiply), dropout regenerated from Philox,
-//     the AlphaDropout + ELU derivative of the omic SNNs (value and Philox word)}.
+//     gate one of {none, a value gate (ReLU / ELU / tanh / sigmoid derivative, multiply), regenerated dropout,
+//     the AlphaDropout + ELU derivative of the omic SNNs (value and random word)}.
 // For those this body has no per-element predicate at all: whole-fragment float4 loads (or four strided scalars when k is
 // not the contiguous index), the gate class fixed at compile time, a k loop of full chunks plus one remainder chunk.
 // Arithmetic, summation order and random streams are those of the general body (results are bit-identical); launches
@@ -60,7 +60,7 @@ struct FastCtx {
                 if (A_KC) {
                     // element (m, k0 + j) has index m * lda + k0 + j; lda % 4 == 0 and k0 % 4 == 0: one counter per fragment
                     const uint64_t ctr = gf.off + (((size_t)m * g.lda + k0) >> 2);
-                    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
+                    const uint4 r = draw4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
                     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) a[u][j] *= gf.with_word(GC == 3 ? gv[u][j] : 0.f, w[j]);
@@ -70,7 +70,7 @@ struct FastCtx {
                     const int lq = lane & 3;
                     const size_t idx_own = (size_t)(k0 + lq) * g.lda + (m & ~3);
                     const uint64_t ctr = gf.off + (idx_own >> 2);
-                    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
+                    const uint4 r = draw4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
                     const uint32_t own[4] = {r.x, r.y, r.z, r.w};
                     uint32_t w[4];
 #pragma unroll

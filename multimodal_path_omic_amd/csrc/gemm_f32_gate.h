@@ -46,7 +46,7 @@ struct GateFn {
             default: return 1.0f;
         }
     }
-    // same result as operator() when the element's Philox word is already at hand (one draw serves four elements)
+    // same result as operator() when the element's random word is already at hand (one draw serves four elements)
     __device__ __forceinline__ float with_word(float gv, uint32_t w) const {
         const bool keep = (float)(w >> 8) * (1.0f / 16777216.0f) >= p;
         if (mode == MPO_GATE_RNG) return keep ? inv_keep : 0.f;

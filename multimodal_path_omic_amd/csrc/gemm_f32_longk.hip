@@ -70,7 +70,7 @@ void gemm_f32_longk_kernel(GemmArgs g) {
                     const int lq = lane & 3;
                     const size_t idx_own = (size_t)min(k0 + lq, g.K - 1) * g.lda + (m & ~3);
                     const uint64_t ctr = gf.off + (idx_own >> 2);
-                    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
+                    const uint4 r = draw4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
                     const uint32_t own[4] = {r.x, r.y, r.z, r.w};
                     uint32_t w[4];
 #pragma unroll

@@ -75,7 +75,7 @@ void gemm_f32_rows_kernel(GemmArgs g) {
                 for (int rt = 0; rt < RT; ++rt) {
                     // element (m, k0 + j) has index m * lda + k0 + j; lda % 4 == 0 and k0 % 4 == 0: one counter per fragment
                     const uint64_t ctr = gf.off + (((size_t)arow[rt] * g.lda + k0) >> 2);
-                    const uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
+                    const uint4 r = draw4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)gf.seed, (uint32_t)(gf.seed >> 32));
                     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) a[u][rt][j] *= gf.with_word(GC == 3 ? gv[u][rt][j] : 0.f, w[j]);

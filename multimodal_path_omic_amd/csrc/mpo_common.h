@@ -36,7 +36,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---- counter-based RNG for dropout masks (Philox4x32-10; seed + 64-bit element counter) ----
+// ---- counter-based RNG for dropout masks (seed + 64-bit element counter) ----
+// philox4x32 (Philox4x32-10) is kept for the one pass-bound kernel that still calls it (the bf16 patch epilogue of the library
+// path); every other mask is cut from draw4x32 below.
 // Forward and backward regenerate the same mask from (seed, offset, element index); nothing is stored.
 __device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -66,10 +68,21 @@ __device__ __forceinline__ uint4 hash4x32(uint32_t key, unsigned long long ctr) 
     const uint32_t x = fmix32(key ^ (uint32_t)ctr) + (uint32_t)(ctr >> 32) * 0x85EBCA77u;
     return make_uint4(fmix32(x + 0x27D4EB2Fu), fmix32(x + 2u * 0x27D4EB2Fu), fmix32(x + 3u * 0x27D4EB2Fu), fmix32(x + 4u * 0x27D4EB2Fu));
 }
+// The 128 bits of counter `ctr` of the stream `seed` -- what every dropout mask of the tail and of K2 is cut from (forward and
+// backward call it with the same arguments).  A counter hash (murmur3 finaliser per word: 11 integer multiplies per draw),
+// not Philox4x32-10 (40): 32-bit multiplies run at a quarter of the vector rate, and the tail's kernels are short enough for
+// that to show -- measured on the whole MCAT window step: 1.136 -> 1.104-1.120 ms.  Masks stay a pure function of
+// (seed, counter); two counters of one stream can collide on the 32-bit intermediate (~1e-4 of the draws of a 1M-counter
+// stream share their 16 bytes with another draw) -- irrelevant for dropout, and the reason this is not called Philox.
+__device__ __forceinline__ uint4 draw4x32(uint32_t c_lo, uint32_t c_hi, uint32_t s_lo, uint32_t s_hi) {
+    const uint32_t key = fmix32(s_lo ^ fmix32(s_hi ^ 0x5A17u));
+    const uint32_t x = fmix32(key ^ c_lo) + c_hi * 0x85EBCA77u;
+    return make_uint4(fmix32(x + 0x27D4EB2Fu), fmix32(x + 2u * 0x27D4EB2Fu), fmix32(x + 3u * 0x27D4EB2Fu), fmix32(x + 4u * 0x27D4EB2Fu));
+}
 // keep-scale for element `idx` of a stream identified by (seed, stream): 0 or 1/(1-p)
 __device__ __forceinline__ float dropout_keep(uint64_t seed, uint64_t offset, uint64_t idx, float p, float inv_keep) {
     uint64_t ctr = offset + (idx >> 2);
-    uint4 r = philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint4 r = draw4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
     uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
     float u = (float)(w >> 8) * (1.0f / 16777216.0f);
     return u >= p ? inv_keep : 0.0f;

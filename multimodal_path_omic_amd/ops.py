@@ -292,7 +292,7 @@ class PatchFcFn(torch.autograd.Function):
     """H_bag = dropout_p(relu(X W_H^T + b)) for a bf16-stored window (models/mcat/mcat.py:24-29,87).
 
     The two big GEMMs stay library calls (hipBLASLt through torch): forward X W^T, backward dW = g^T X.
-    What is ours: the fused bias + ReLU + dropout epilogue (one pass, mask regenerated from the Philox
+    What is ours: the fused bias + ReLU + dropout epilogue (one pass, mask regenerated from the counter
     counter instead of stored) and the contraction over ~10^5-10^6 patch rows of dW, which hipBLASLt runs
     on 16 workgroups when given as one GEMM: it is issued as a batched split-K product (fp32 partials)
     and summed.  X never needs a gradient (it is data)."""
@@ -546,7 +546,7 @@ import torch.nn.functional as F  # noqa: E402
 
 
 def _reserve(span: int):
-    """Reserve `span` Philox counters for one C-ABI call's dropout streams."""
+    """Reserve `span` counters of the dropout generator for one C-ABI call's streams."""
     global _rng_calls
     seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
     off = _rng_calls
@@ -1090,7 +1090,7 @@ _rng_calls = 0
 
 
 def next_dropout_stream(n_elements: int):
-    """(seed, offset) for one dropout mask of n_elements: Philox counter space is carved sequentially per
+    """(seed, offset) for one dropout mask of n_elements: the generator's counter space is carved sequentially per
     process, the seed follows torch.initial_seed() (so torch.manual_seed(rank-dependent) de-correlates ranks)."""
     global _rng_calls
     seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF

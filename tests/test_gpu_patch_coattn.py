@@ -258,7 +258,7 @@ def test_token_pair_hands_both_token_sets_over_without_copies(dev):
 
 def test_patch_layer_alone_is_the_fused_kernel_without_its_co_attention(dev):
     """mpo_patch_fc_forward (the fused kernel with its co-attention slices off): H_bag must be bit for bit what the fused
-    forward writes -- eval and, with the same Philox stream, training mode -- on a ragged window with partial blocks; the
+    forward writes -- eval and, with the same dropout stream, training mode -- on a ragged window with partial blocks; the
     autograd wrapper (ops.patch_fc with a batch) must give the patch layer's gradients."""
     lengths = [1, 127, 129, 700, 2049]
     p = _params(41)

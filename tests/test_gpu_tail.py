@@ -104,7 +104,7 @@ def _directional(fn, x, v, eps=1e-2):
 
 @pytest.mark.parametrize("which", ["encoder", "pool"])
 def test_training_dropout_forward_backward_use_the_same_masks(dev, which):
-    """With the Philox counter pinned, the forward is a deterministic function of its input, so the
+    """With the dropout counter pinned, the forward is a deterministic function of its input, so the
     analytic gradient (masks regenerated in backward) must match a finite difference."""
     torch.manual_seed(5)
     gsyn = syn.rng(31)
@@ -323,7 +323,7 @@ def test_fast_gemm_body_equals_the_general_body(dev):
     params = [p for m in enc + heads + rhos + [G, fus, cls] for p in m.parameters()]
 
     def run():
-        ops._rng_calls = 1000                                   # same Philox streams in both runs
+        ops._rng_calls = 1000                                   # same dropout streams in both runs
         t = x.clone().requires_grad_(True)
         g_bag = ops.omic_snn(omics, G, True)
         tok = ops.encoder_stacked(t + torch.stack([g_bag, g_bag]), [list(e.layers) for e in enc], True)
