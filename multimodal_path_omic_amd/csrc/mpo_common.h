@@ -64,17 +64,24 @@ __device__ __forceinline__ uint32_t hash_stream_key(unsigned long long seed, uns
     k = fmix32(k ^ (uint32_t)offset);
     return fmix32(k ^ (uint32_t)(offset >> 32));
 }
+// (-DMPO_DRAW_PHILOX builds every mask from Philox4x32-10 again: the A/B switch of tools/build_variant.py, not a product mode)
 __device__ __forceinline__ uint4 hash4x32(uint32_t key, unsigned long long ctr) {
+#ifdef MPO_DRAW_PHILOX
+    return philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, key, 0x5A17u);
+#endif
     const uint32_t x = fmix32(key ^ (uint32_t)ctr) + (uint32_t)(ctr >> 32) * 0x85EBCA77u;
     return make_uint4(fmix32(x + 0x27D4EB2Fu), fmix32(x + 2u * 0x27D4EB2Fu), fmix32(x + 3u * 0x27D4EB2Fu), fmix32(x + 4u * 0x27D4EB2Fu));
 }
 // The 128 bits of counter `ctr` of the stream `seed` -- what every dropout mask of the tail and of K2 is cut from (forward and
 // backward call it with the same arguments).  A counter hash (murmur3 finaliser per word: 11 integer multiplies per draw),
 // not Philox4x32-10 (40): 32-bit multiplies run at a quarter of the vector rate, and the tail's kernels are short enough for
-// that to show -- measured on the whole MCAT window step: 1.136 -> 1.104-1.120 ms.  Masks stay a pure function of
+// that to show -- same-box A/B of the whole MCAT window step (tools/build_variant.py): 1.143-1.150 -> 1.126-1.130 ms.  Masks stay a pure function of
 // (seed, counter); two counters of one stream can collide on the 32-bit intermediate (~1e-4 of the draws of a 1M-counter
 // stream share their 16 bytes with another draw) -- irrelevant for dropout, and the reason this is not called Philox.
 __device__ __forceinline__ uint4 draw4x32(uint32_t c_lo, uint32_t c_hi, uint32_t s_lo, uint32_t s_hi) {
+#ifdef MPO_DRAW_PHILOX
+    return philox4x32(c_lo, c_hi, 0u, 0u, s_lo, s_hi);
+#endif
     const uint32_t key = fmix32(s_lo ^ fmix32(s_hi ^ 0x5A17u));
     const uint32_t x = fmix32(key ^ c_lo) + c_hi * 0x85EBCA77u;
     return make_uint4(fmix32(x + 0x27D4EB2Fu), fmix32(x + 2u * 0x27D4EB2Fu), fmix32(x + 3u * 0x27D4EB2Fu), fmix32(x + 4u * 0x27D4EB2Fu));
