@@ -260,6 +260,17 @@ def cpu_baseline_leg(kind, patches, budget_s=15.0):
             "sample": f"{n} slides of {patches}x1024 fp32, {kind} medium, fwd+ces+bwd, one slide per call"}
 
 
+def _all_ranks_ok(ok: bool, dev, world) -> bool:
+    """Collective agreement on a per-rank outcome: True only if EVERY rank reports ok (MIN all-reduce; identity at N = 1)."""
+    if world == 1:
+        return ok
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
     """Build the model and its resident windows, time `steps` window steps (barrier + synchronize on both sides, max over
     ranks) and return the contract dict (rank 0; None elsewhere)."""
@@ -299,7 +310,10 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
         except Exception as e:                                    # same kernels either way; say so in the output
             graphed, graph_note = None, f"eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})"
             torch.cuda.synchronize(dev)
-
+        # The graphed and the eager step issue DIFFERENT collective sequences (two split all-reduces around the dW_H graph
+        # against one): the choice must be the same on every rank, or the ranks hang in mismatched collectives.
+        if not _all_ranks_ok(graphed is not None, dev, world) and graphed is not None:
+            graphed, graph_note = None, "eager (graph capture failed on another rank)"
     def step(i):
         if graphed is None:
             return eager_step(i)
@@ -421,12 +435,18 @@ def extras(a, dev, rank, world):
     out = {}
     for name, over, roof in plan:
         b = argparse.Namespace(**{**vars(a), **over})
+        err = None
         try:
             r = run_config(b, dev, rank, world, steps=max(5, min(a.steps, 10)), warmup=2, with_roofline=roof)
         except Exception as e:                                    # an extra must never take the headline line down
-            r = {"error": f"{type(e).__name__}: {str(e)[:200]}"} if rank == 0 else None
+            err, r = f"{type(e).__name__}: {str(e)[:200]}", None
+        if world > 1 and err is not None:
+            # a rank that left run_config() early has skipped collectives its peers are still waiting in: there is no
+            # sequence to rejoin.  Fail the job (the launcher tears the other ranks down) rather than hang until the timeout.
+            print(f"[bench] rank {rank}: extra '{name}' failed ({err}); aborting the multi-rank run", file=sys.stderr, flush=True)
+            os._exit(3)
         if rank == 0:
-            out[name] = r
+            out[name] = r if err is None else {"error": err}
     if world == 1:
         try:
             out["f3_ge_nacagat_15k"] = ge_extra(dev)

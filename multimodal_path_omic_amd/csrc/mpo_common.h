@@ -64,27 +64,25 @@ __device__ __forceinline__ uint32_t hash_stream_key(unsigned long long seed, uns
     k = fmix32(k ^ (uint32_t)offset);
     return fmix32(k ^ (uint32_t)(offset >> 32));
 }
-// (-DMPO_DRAW_PHILOX builds every mask from Philox4x32-10 again: the A/B switch of tools/build_variant.py, not a product mode)
+// The 128 bits of counter `ctr` under a 32-bit stream key.  The key enters twice: XOR-ed into the counter before the first
+// finaliser round AND as the (odd) stride between the four output words, so two streams are not the same set of draws at
+// permuted counters (with the key in the first round only, stream B's counter c ^ kA ^ kB reproduced stream A's counter c:
+// per-rank seeds would have shared their masks up to a permutation).  What remains: all 128 bits hang off one 32-bit
+// intermediate x, so inside ONE stream two counters collide on x with probability 2^-32 per pair (~1e-4 of the draws of a
+// 1M-counter stream share their 16 bytes with another draw) -- irrelevant for dropout, and the reason this is not called Philox.
+__device__ __forceinline__ uint32_t hash_word_stride(uint32_t key) { return fmix32(key ^ 0x9E3779B9u) | 1u; }
 __device__ __forceinline__ uint4 hash4x32(uint32_t key, unsigned long long ctr) {
-#ifdef MPO_DRAW_PHILOX
-    return philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, key, 0x5A17u);
-#endif
     const uint32_t x = fmix32(key ^ (uint32_t)ctr) + (uint32_t)(ctr >> 32) * 0x85EBCA77u;
-    return make_uint4(fmix32(x + 0x27D4EB2Fu), fmix32(x + 2u * 0x27D4EB2Fu), fmix32(x + 3u * 0x27D4EB2Fu), fmix32(x + 4u * 0x27D4EB2Fu));
+    const uint32_t inc = hash_word_stride(key);                 // (wave-uniform: the compiler keeps it on the scalar unit)
+    return make_uint4(fmix32(x + inc), fmix32(x + 2u * inc), fmix32(x + 3u * inc), fmix32(x + 4u * inc));
 }
-// The 128 bits of counter `ctr` of the stream `seed` -- what every dropout mask of the tail and of K2 is cut from (forward and
-// backward call it with the same arguments).  A counter hash (murmur3 finaliser per word: 11 integer multiplies per draw),
-// not Philox4x32-10 (40): 32-bit multiplies run at a quarter of the vector rate, and the tail's kernels are short enough for
-// that to show -- same-box A/B of the whole MCAT window step (tools/build_variant.py): 1.143-1.150 -> 1.126-1.130 ms.  Masks stay a pure function of
-// (seed, counter); two counters of one stream can collide on the 32-bit intermediate (~1e-4 of the draws of a 1M-counter
-// stream share their 16 bytes with another draw) -- irrelevant for dropout, and the reason this is not called Philox.
+// The 128 bits of counter (c_lo, c_hi) of the stream `seed` -- what every dropout mask of the tail and of K2 is cut from
+// (forward and backward call it with the same arguments).  A counter hash (murmur3 finaliser per word: 11 vector integer
+// multiplies per draw), not Philox4x32-10 (40): 32-bit multiplies run at a quarter of the vector rate, and the tail's kernels
+// are short enough for that to show -- same-box A/B of the whole MCAT window step in r02: 1.143-1.150 -> 1.126-1.130 ms.
+// Masks stay a pure function of (seed, counter).
 __device__ __forceinline__ uint4 draw4x32(uint32_t c_lo, uint32_t c_hi, uint32_t s_lo, uint32_t s_hi) {
-#ifdef MPO_DRAW_PHILOX
-    return philox4x32(c_lo, c_hi, 0u, 0u, s_lo, s_hi);
-#endif
-    const uint32_t key = fmix32(s_lo ^ fmix32(s_hi ^ 0x5A17u));
-    const uint32_t x = fmix32(key ^ c_lo) + c_hi * 0x85EBCA77u;
-    return make_uint4(fmix32(x + 0x27D4EB2Fu), fmix32(x + 2u * 0x27D4EB2Fu), fmix32(x + 3u * 0x27D4EB2Fu), fmix32(x + 4u * 0x27D4EB2Fu));
+    return hash4x32(fmix32(s_lo ^ fmix32(s_hi ^ 0x5A17u)), ((unsigned long long)c_hi << 32) | c_lo);
 }
 // keep-scale for element `idx` of a stream identified by (seed, stream): 0 or 1/(1-p)
 __device__ __forceinline__ float dropout_keep(uint64_t seed, uint64_t offset, uint64_t idx, float p, float inv_keep) {

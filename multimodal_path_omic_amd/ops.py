@@ -396,9 +396,11 @@ def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk
 
 def patch_weight_grad(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """dW_H = g^T x into `out` (embed, patch_dim) fp32: the hand-written kernel (mpo_patch_weight_grad) for a bf16 window
-    at embed 256 / patch_dim a multiple of 256, the library split-K product otherwise."""
+    at embed 256 / patch_dim 256, 512, 1024 or 2048 whose patch matrix stays below 4 GiB (the launcher's conditions:
+    32-bit DMA offsets, 256 row ranges per column block), the library split-K product otherwise."""
     e, k = out.shape
-    if (g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and e == 256 and k % 256 == 0 and 256 <= k <= 2048
+    if (g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and e == 256 and k in (256, 512, 1024, 2048)
+            and g.shape[0] * k * 2 < 2 ** 32
             and g.is_contiguous() and x.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32):
         lib = L.lib()
         ws = _workspace(lib.mpo_patch_weight_grad_workspace_bytes(e, k), g.device)

@@ -51,18 +51,21 @@ def _store(t, dtype):
     return t if dtype is None else t.to(dtype).float()
 
 
-def patch_fc(wsi, p, prefix="H", keep=None, storage=None, round_gemm_out=True):
+def patch_fc(wsi, p, prefix="H", keep=None, storage=None, round_gemm_out=True, storage_points=("x", "w", "h")):
     """H_bag = Drop(ReLU(X W_H^T + b)); models/mcat/mcat.py:24-29,87.
     storage=torch.bfloat16 emulates the product's bf16 STORAGE points with fp32 arithmetic in between, so a bf16-stored
     run can be checked tightly: patch matrix, GEMM weight operand, H_bag -- and, with round_gemm_out, the GEMM output
     before the bias (the library-GEMM path of the small / big models; the hand-written patch-layer kernel of the medium
-    models keeps the accumulator in fp32 up to the one rounding of H_bag)."""
+    models keeps the accumulator in fp32 up to the one rounding of H_bag).
+    storage_points: which of the three storage points are rounded -- "x" the patch matrix, "w" the weight operand,
+    "h" H_bag (and the GEMM output under round_gemm_out) -- so a test can attribute a bf16-mode error to each of them."""
     x = wsi.squeeze(0) if wsi.dim() == 3 else wsi
-    x = _store(x.float(), storage)
-    h = x @ _store(p[prefix + ".0.weight"], storage).t()
+    x = _store(x.float(), storage if "x" in storage_points else None)
+    h = x @ _store(p[prefix + ".0.weight"], storage if "w" in storage_points else None).t()
+    st_h = storage if "h" in storage_points else None
     if round_gemm_out:
-        h = _store(h, storage)
-    h = _store(torch.relu(h + p[prefix + ".0.bias"]), storage)
+        h = _store(h, st_h)
+    h = _store(torch.relu(h + p[prefix + ".0.bias"]), st_h)
     return h if keep is None else h * keep
 
 
@@ -241,19 +244,20 @@ def _tail(h_coattn, g_bag, a_coattn, p, fusion="concat"):
     return hazards, survs, y, {"coattn": a_coattn, "path": a_path, "omic": a_omic}
 
 
-def mcat_forward(p, wsi, omics, inference=False, bag_storage=None, fusion="concat", round_gemm_out=False):
+def mcat_forward(p, wsi, omics, inference=False, bag_storage=None, fusion="concat", round_gemm_out=False,
+                 storage_points=("x", "w", "h")):
     """MultimodalCoAttentionTransformer.forward, models/mcat/mcat.py:84-142 (eval mode).
     bag_storage / round_gemm_out: see patch_fc (the fused kernel of the 'medium' model rounds H_bag once)."""
-    h_bag = patch_fc(wsi, p, storage=bag_storage, round_gemm_out=round_gemm_out)
+    h_bag = patch_fc(wsi, p, storage=bag_storage, round_gemm_out=round_gemm_out, storage_points=storage_points)
     g_bag = omic_fc(omics, p)
     h_co, a_co = mcat_coattention(g_bag, h_bag, p, need_weights=inference)
     return _tail(h_co, g_bag, a_co, p, fusion)
 
 
-def nacagat_forward(p, wsi, omics, bag_storage=None, round_gemm_out=False):
+def nacagat_forward(p, wsi, omics, bag_storage=None, round_gemm_out=False, storage_points=("x", "w", "h")):
     """NarrowContextualAttentionGateTransformer.forward, models/nacagat/nacagat.py:80-138 (eval mode).
     bag_storage / round_gemm_out: see patch_fc (the 'medium' model's patch-layer kernel rounds H_bag once)."""
-    h_bag = patch_fc(wsi, p, storage=bag_storage, round_gemm_out=round_gemm_out)
+    h_bag = patch_fc(wsi, p, storage=bag_storage, round_gemm_out=round_gemm_out, storage_points=storage_points)
     g_bag = omic_fc(omics, p)
     h_co, a_co = pregating_contextual_attention(g_bag, h_bag, p)
     return _tail(h_co, g_bag, a_co, p)

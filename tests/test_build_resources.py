@@ -58,9 +58,10 @@ def test_headline_kernels_are_register_resident(usage):
             assert v["scratch_bytes"] == 0 and v["vgpr_spill"] == 0, (h, v)
 
 
-@pytest.mark.parametrize("source", ["coattn_fwd.hip", "bag_selfattn.hip"])
+@pytest.mark.parametrize("source", ["coattn_fwd.hip", "bag_selfattn.hip", "patch_coattn_fwd.hip", "patch_wgrad.hip"])
 def test_m0_is_only_touched_by_the_direct_to_lds_loads(tmp_path, source):
-    """K1 forward (and the head-dimension-256 bag self-attention kernels) issue their tile loads from inline asm that sets
+    """K1 forward, the fused patch-layer kernel (the headline kernel), the patch-layer weight gradient and the
+    head-dimension-256 bag self-attention kernels issue their tile loads from inline asm that sets
     M0 (the LDS destination of global_load_lds_dwordx4) and lists it as clobbered, which the compiler only honours as long
     as it has no use of M0 of its own in that kernel.  Compile the file to assembly and check that every M0 access sits
     inside one of those asm blocks."""

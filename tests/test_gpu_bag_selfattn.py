@@ -232,7 +232,7 @@ def test_ge_model_matches_reference_golden(dev, golden, case):
     for got, key in ((sub(att["attn"]), "A_attn_sub"), (att["attn"].max(dim=1).values, "A_attn_rowmax"),
                      (att["attn"].diagonal(), "A_attn_diag")):
         ref = g[f"{case}/{key}"]
-        assert ((got.cpu() - ref).abs() / ref.clamp_min(1e-30)).max().item() < 2e-3, key
+        assert ((got.cpu() - ref).abs() / ref.clamp_min(1e-30)).max().item() < 1e-3, key
     loss = torch.nn.functional.cross_entropy(y.unsqueeze(0), target.to(dev))         # models/ge_nacagat/main.py:33
     assert abs(loss.item() - float(g[f"{case}/loss"])) < 1e-4
     loss.backward()
@@ -289,7 +289,7 @@ def test_ge_model_small_equals_oracle_and_big_is_refused(dev):
     yo, atto = O.ge_nacagat_forward(p, wsi)
     assert float((y.detach().cpu() - yo).abs().max()) < 1e-4
     assert relmax(att["path"], atto["path"]) < 1e-3
-    assert ((att["attn"].cpu() - atto["attn"]).abs() / atto["attn"].clamp_min(1e-30)).max().item() < 2e-3
+    assert ((att["attn"].cpu() - atto["attn"]).abs() / atto["attn"].clamp_min(1e-30)).max().item() < 1e-3
     torch.nn.functional.cross_entropy(y.unsqueeze(0), target.to(dev)).backward()
     O.ge_ce_loss(yo, target).backward()
     for n, prm in model.named_parameters():

@@ -10,6 +10,10 @@ from multimodal_path_omic_amd.blocks import ContextualAttentionGate, PreGatingCo
 from oracle import mpo_oracle as O
 
 pytestmark = pytest.mark.gpu
+# gradient bars = about twice the measured worst case (printed per case, pytest -rA)
+GRAD_TOL_PEAKY = 1e-2
+GRAD_TOL_BF16_BAG = 1.5e-2
+GRAD_TOL_BF16_PARAM = 5e-3
 sub = syn.subsample
 
 
@@ -71,24 +75,28 @@ def test_nacagat_forward_backward(dev, golden, case, dtype):
     peaky = "peaky" in case
     assert relerr(out, out_o) < (1e-3 if peaky else 2e-4), relerr(out, out_o)
     rel_a = ((a.detach().cpu() - a_o.detach()).abs() / a_o.detach().clamp_min(1e-30)).max().item()
-    # fp32 bag: both score products run on the fp32-input MFMA (bag_rowdot_gated_exact), so the map holds
-    # the north-star 1e-3 on the deliberately peaky fixture too; a bf16 bag reaches K through the bf16
-    # key projection, whose rounding the gate multiplies (dS = (g+1) da) on that fixture
+    # both score products run on the fp32-input MFMA (bag_rowdot_gated_exact) and a bf16 bag reaches K through the
+    # three-term key projection (fp32-exact weights): the map holds the north-star 1e-3 on the deliberately peaky
+    # fixture in both storage modes (measured r02: 2.3e-4 fp32 bag, 5.4e-4 bf16 bag)
     print(f"[K2 map] {case} {dtype}: rel_a {rel_a:.3e}")
-    assert rel_a < (2e-3 if (peaky and not f32) else 1e-3), rel_a
+    assert rel_a < 1e-3, rel_a
     torch.testing.assert_close(a.sum(1).cpu(), torch.ones(C.N_OMIC), rtol=1e-4, atol=1e-4)
     params = dict(mod.named_parameters())
     tensors = [qd, bd] + [params[k[len("co_attention."):]] for k in p]
     names = ["query", "bag"] + list(p)
     gs = torch.autograd.grad((out * p_out.to(dev)).sum() + (a * p_a.to(dev)).sum(), tensors)
+    worst = {}
     for n, gr in zip(names, gs):
-        tol = 1e-2 if peaky else 2e-3
+        tol = GRAD_TOL_PEAKY if peaky else 2e-3
         if not f32:
             # bf16 bag: d_bag is emitted in bf16 and the key-projection gradients (dW_k, dH += dK W_k) run
             # through bf16 operands with fp32 accumulation
-            tol = 1.5e-2 if n == "bag" else max(tol, 5e-3)
+            tol = GRAD_TOL_BF16_BAG if n == "bag" else max(tol, GRAD_TOL_BF16_PARAM)
         e = relerr(gr, g1_o[n])
+        worst[n] = e
         assert e < tol, (n, e)
+    wn = max(worst, key=worst.get)
+    print(f"[K2 grads] {case} {dtype}: worst {worst[wn]:.3e} at {wn}; bag {worst['bag']:.3e} query {worst['query']:.3e}")
     if f32:
         g = golden("coattn_nacagat")
         assert relerr(out, g[f"{case}/out"]) < 1e-3

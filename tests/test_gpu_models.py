@@ -54,7 +54,7 @@ def test_model_matches_reference_golden(dev, golden, case):
     assert relerr(att["path"], g[f"{case}/A_path"]) < 1e-3
     assert relerr(att["omic"], g[f"{case}/A_omic"]) < 1e-3
     ga = g[f"{case}/A_coattn_sub"]
-    assert ((sub(att["coattn"]).cpu() - ga).abs() / ga.clamp_min(1e-30)).max().item() < 2e-3
+    assert ((sub(att["coattn"]).cpu() - ga).abs() / ga.clamp_min(1e-30)).max().item() < 1e-3        # the north-star map bar
     loss = ces_loss(hz, sv, label.to(dev), censor.to(dev))
     assert abs(loss.item() - float(g[f"{case}/loss"])) < 1e-4
     loss.backward()
@@ -107,7 +107,13 @@ def test_model_bf16_bag_vs_fp32_reference_golden(dev, golden, case, record_prope
         by 3.1e-3 (MCAT) / 2.9e-2 (NaCAGaT: the narrow gate multiplies the logit error), so 1e-3 on the map is not
         reachable in this storage mode by any kernel.  What the kernels must NOT do is add to the storage rounding: the
         error against the fp32 reference is held to the error the ORACLE makes when it is fed the same stored values
-        (bag_storage=bf16; fp32 arithmetic), +25 %, and to a fraction of it against that same-storage oracle.
+        (bag_storage=bf16; fp32 arithmetic), +25 %, and to a fraction of it against that same-storage oracle.  Where that
+        floor comes from, storage point by storage point (X / W_H / H_bag: 3.1e-3 / 3.2e-3 / 3.6e-3 alone, 5.2e-3 together
+        for MCAT at M = 15 000), is pinned on the CPU by test_oracle_golden.py::test_bf16_storage_map_error_by_storage_point.
+      * the pooling map over the 6 co-attended tokens ('path'): the same rule -- 1e-3 where the storage floor allows it
+        (MCAT: 1.5e-4), else the same-storage oracle's own error + 25 % (NaCAGaT: 8.3e-3 from storage alone).
+      * fixed ceilings pinned to the measured values on top of the relative-to-floor bars: a change that moved the oracle's
+        storage emulation together with the kernels would still be caught.
     The measured margins are printed (pytest -rA) and quoted in DESIGN.md section 4."""
     g = golden("models")
     kind, m, omic_sizes, seed = C.MODEL_CASES[case]
@@ -129,11 +135,14 @@ def test_model_bf16_bag_vs_fp32_reference_golden(dev, golden, case, record_prope
         _, _, _, att_s = fwd(sd, wsi, omics, bag_storage=torch.bfloat16, **kw)       # same stored values, fp32 arithmetic
         _, _, _, att_x = fwd(sd, wsi.bfloat16().float(), omics, **kw)                # ONLY the patch matrix rounded
     floor_s, floor_x = map_rel(sub(att_s["coattn"]), ga), map_rel(sub(att_x["coattn"]), ga)
+    floor_p = relerr(att_s["path"], g[f"{case}/A_path"])
     e_same = map_rel(sub(att["coattn"]).cpu(), sub(att_s["coattn"]))
-    print(f"[bf16 vs fp32 reference] {case}: hazards {e_h:.2e} survs {e_s:.2e} Y {e_y:.2e} path map rel {e_p:.2e} | coattn map rel "
+    print(f"[bf16 vs fp32 reference] {case}: hazards {e_h:.2e} survs {e_s:.2e} Y {e_y:.2e} path map rel {e_p:.2e} (same-storage oracle "
+          f"{floor_p:.2e}) | coattn map rel "
           f"{e_a:.2e} (oracle on the same stored values {floor_s:.2e}; patch matrix rounded alone {floor_x:.2e}); vs same-storage oracle {e_same:.2e}")
     for k, v in (("hazards", e_h), ("survs", e_s), ("Y", e_y), ("coattn_rel", e_a), ("coattn_rel_storage_floor", floor_s),
-                 ("coattn_rel_patch_rounding_only", floor_x), ("coattn_rel_vs_same_storage_oracle", e_same), ("path_rel", e_p)):
+                 ("coattn_rel_patch_rounding_only", floor_x), ("coattn_rel_vs_same_storage_oracle", e_same), ("path_rel", e_p),
+                 ("path_rel_storage_floor", floor_p)):
         record_property(f"{case}/{k}", v)
     assert e_h < 1e-3 and e_s < 1e-3 and e_y < 1e-3, (e_h, e_s, e_y)
     assert e_a < 1.25 * floor_s + 2e-4, (e_a, floor_s)
@@ -141,6 +150,10 @@ def test_model_bf16_bag_vs_fp32_reference_golden(dev, golden, case, record_prope
     # different orders, round to different bf16 neighbours (a 2^-8 step of one element of a 256-term logit): a fraction of
     # the storage rounding itself
     assert e_same < 0.6 * floor_s + 2e-4, (e_same, floor_s)
+    assert e_p < max(1e-3, 1.25 * floor_p + 2e-4), (e_p, floor_p)
+    # fixed ceilings (measured r02/r03: MCAT map 5.2e-3, path 1.5e-4 / 4.1e-4; NaCAGaT map 5.3e-2, path 9.4e-3 / 2.8e-3)
+    assert e_a < (6.5e-3 if kind == "mcat" else 6.5e-2), e_a
+    assert e_p < (1e-3 if kind == "mcat" else 1.3e-2), e_p
 
 
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])

@@ -92,6 +92,19 @@ def test_fused_forward_and_gradients_match_oracle(dev, lengths, gain):
     rel = float(((a - a_k).abs() / a_k.clamp_min(1e-30)).max())
     print(f"[f1 map] {lengths[0]} rows, gain {gain}: rel err {rel:.2e} vs the oracle on the kernel's H_bag")
     assert rel < 1e-3, rel
+    # The COMPOSED check, end to end against the same-storage oracle (its own H_bag): the only admissible extra error is what
+    # the one-ulp H_bag differences bounded above can do to a logit.  With s[n][m] = qk[n] . H[m] (qk = (q W_q^T + b_q) W_k /
+    # sqrt(E), the folded query) a perturbation dH moves logit (n, m) by at most sum_d |qk[n][d]| |dH[m][d]| =: ds[n][m], and a
+    # softmax entry by at most exp(2 max ds) - 1 relative (its own logit up, the normaliser down); on top of that the
+    # arithmetic bar of the check above.
+    w_in, b_in = p["co_attention.in_proj_weight"], p["co_attention.in_proj_bias"]
+    qk = ((query @ w_in[:E].t() + b_in[:E]) / math.sqrt(E)) @ w_in[E:2 * E]
+    ds_max = float((qk.abs() @ hd.t()).max())
+    rel_e2e = float(((a - a_o.detach()).abs() / a_o.detach().clamp_min(1e-30)).max())
+    bound = math.expm1(2.0 * ds_max) + 1e-3
+    print(f"[f1 map, composed] {lengths[0]} rows, gain {gain}: rel err {rel_e2e:.2e} vs the same-storage oracle end to end; "
+          f"bound from the H_bag one-ulp differences {bound:.2e} (max logit shift {ds_max:.2e})")
+    assert rel_e2e < bound, (rel_e2e, bound)
     assert relmax(out.detach().cpu(), out_o.detach()) < 2e-3 * gain * gain
     probe_o, probe_a = syn.normal(syn.rng(5), (N_Q, E)), syn.normal(syn.rng(6), (N_Q, lengths[0]))
     ((out * probe_o.to(dev)).sum() + (amap.view(N_Q, -1) * probe_a.to(dev)).sum()).backward()

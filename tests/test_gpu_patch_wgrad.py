@@ -48,3 +48,16 @@ def test_unsupported_shapes_take_the_library_path(dev):
     out = torch.empty(128, 1024, device=dev)
     ops.patch_weight_grad(g, x, out)
     torch.testing.assert_close(out.double(), _ref(g, x), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("patch_dim", [768, 1280])
+def test_patch_dims_the_launcher_refuses_take_the_library_path(dev, patch_dim):
+    """embed 256 but a patch width the kernel's 256-row-range split does not divide (the launcher wants 256 % (k / 256) == 0):
+    the Python gate must route these to the library product instead of raising in backward."""
+    gen = torch.Generator(device=dev).manual_seed(patch_dim)
+    g = (torch.randn(3000, 256, device=dev, generator=gen) * 0.1).to(torch.bfloat16)
+    x = torch.randn(3000, patch_dim, device=dev, generator=gen).to(torch.bfloat16)
+    out = torch.empty(256, patch_dim, device=dev)
+    ops.patch_weight_grad(g, x, out)
+    ref = _ref(g, x)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-4
