@@ -271,6 +271,28 @@ def _all_ranks_ok(ok: bool, dev, world) -> bool:
     return bool(t.item())
 
 
+def ge_cpu_baseline_leg(patches=15000):
+    """Row f3's CPU baseline: the oracle's gene-expression model (kind 'port') on ONE bag of the benchmarked length -- forward,
+    cross-entropy, backward, fp32, all host threads.  One slide is the bounded sample: the reference algorithm keeps the
+    8-head M x M probabilities of both encoder layers for the backward (~45 GB at M = 15 000) and takes tens of seconds."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases as C
+    from multimodal_path_omic_amd import synthetic as syn
+    from oracle import mpo_oracle as O
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    sd = syn.fill_state_dict(C.ge_model_shapes(), 2)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    wsi = syn.make_bag(patches, 78)
+    t0 = time.perf_counter()
+    y, _ = O.ge_nacagat_forward(p, wsi)
+    O.ge_ce_loss(y, torch.tensor([1])).backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "slides/s", "cores": threads, "kind": "port",
+            "sample": f"1 slide of {patches}x1024 fp32, GE-NaCAGaT medium, fwd+CE+bwd ({dt:.1f} s)"}
+
+
 def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
     """Build the model and its resident windows, time `steps` window steps (barrier + synchronize on both sides, max over
     ranks) and return the contract dict (rank 0; None elsewhere)."""
@@ -485,6 +507,12 @@ def main():
     # (measured: the ragged extra at 1.92 ms per step after it, 1.47 ms before it)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(a.model, a.patches)
+        f3 = out.get("extra", {}).get("f3_ge_nacagat_15k")
+        if isinstance(f3, dict) and "error" not in f3:
+            try:
+                f3["cpu_baseline"] = ge_cpu_baseline_leg()
+            except Exception as e:                                # (host memory: the oracle materialises the M x M maps)
+                f3["cpu_baseline"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -106,6 +106,21 @@ int mpo_patch_fc_forward(const void* patches, const int32_t* cu_rows, int n_slid
                          const float* patch_weight, const float* patch_bias, int embed, float drop_p, uint64_t seed,
                          uint64_t offset, const uint64_t* rng_epoch, void* h_bag, const mpo_bag_plan* plan /* nullable */,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+/* The patch layer of an fp32-stored window (models/mcat/mcat.py:24-29,87 with fp32 patch features; ABI v11), 1024 -> 256:
+ *   forward   H_bag = Dropout(ReLU(X W^T + b)) in fp32 storage; products as three bf16 MFMA terms of hi / lo operand splits with fp32
+ *             accumulation (csrc/patch_fc_f32.hip).  Dropout: counter hash, 8 bits per element (realised p = round(256 p) / 256);
+ *             the mask lives in H_bag as zeros.
+ *   backward  d_weight = g^T X, d_bias = colsum(g) with g = d_h_bag (.) [H_bag > 0] * gate; gate = 1 / (1 - realised p)
+ *             (1 without dropout); h_bag NULL: g = d_h_bag.  X needs no gradient (it is data).
+ * workspace: caller-owned, mpo_patch_fc_f32_workspace_bytes(backward) bytes. */
+size_t mpo_patch_fc_f32_workspace_bytes(int backward);
+int mpo_patch_fc_f32_forward(const float* patches, int64_t total_rows, int patch_dim, const float* patch_weight,
+                             const float* patch_bias, int embed, float drop_p, uint64_t seed, uint64_t offset,
+                             const uint64_t* rng_epoch, float* h_bag, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+int mpo_patch_fc_f32_backward(const float* d_h_bag, const float* h_bag /* nullable */, const float* patches, int64_t total_rows,
+                              int embed, int patch_dim, float gate, float* d_weight, float* d_bias, void* workspace,
+                              size_t workspace_bytes, mpo_stream_t stream);
+
 /* The fused bag pass alone (measurement): w_packed = embed * patch_dim bf16 values from mpo_pack_patch_weight (the weight
  * in the fragment order of the kernel's GEMM waves), qk2 [n_slides*n_q, embed]. */
 int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_packed, const float* bias, const int32_t* cu_rows, int n_slides,
@@ -169,6 +184,11 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
  * (whole 16 x 16 tiles, K % 64 == 0, aligned operands, a gate known at compile time) and a general body otherwise; the two
  * are bit-identical.  enabled = 0 sends everything through the general body.  Returns the previous setting (default 1). */
 int mpo_set_gemm_fast_path(int enabled);
+
+/* Verification hook (tests): K1's backward bag pass has a two-waves-per-SIMD kernel for a bf16 bag at embed_dim 256 with at most 8
+ * queries and no gradient on the map (csrc/coattn_bwd8.hip) and a general kernel for everything else (csrc/coattn_bwd.hip).
+ * enabled = 0 sends every geometry through the general kernel.  Returns the previous setting (default 1).  ABI v11. */
+int mpo_set_coattn_bwd_two_wave(int enabled);
 
 /* rng_epoch += 1 and adam_step += 1 (either may be NULL) in one launch: the per-step device counters of a captured
  * training step (dropout epoch of every mpo_*_forward, step count of mpo_adam_step_flat). */
@@ -237,6 +257,17 @@ int mpo_nacagat_patch_grad(const int32_t* cu_rows, int n_slides, int total_rows,
                            const float* attn_map, const float* d_ctx, const void* addend_bf16, const void* hbag_bf16,
                            void* d_bag_bf16, float relu_gate, float* d_bias, const mpo_bag_plan* plan /* nullable */,
                            void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+
+/* The same gradient with the product back through the key projection INSIDE the pass (ABI v11; embed_dim 256):
+ *   d_bag[m][e'] = ( sum_e d_kbag[m][e] W_k[e][e'] + sum_q attn_map[q][m] d_ctx[q][e'] ) * (hbag[m][e'] > 0 ? relu_gate : 0)
+ * d_kbag bf16 [total_rows, embed] as mpo_coattn_nacagat_backward emits it, w_k = in_proj_weight rows [embed, 2 embed) (fp32,
+ * [embed][embed]); reads d_kbag and hbag once, writes d_bag once -- no library GEMM, no second pass.  d_bag must not alias
+ * d_kbag (the caller still needs it for dW_k). */
+int mpo_nacagat_patch_grad_fused(const int32_t* cu_rows, int n_slides, int total_rows, int max_rows, int n_q, int embed,
+                                 const float* attn_map, const float* d_ctx, const void* d_kbag_bf16, const float* w_k,
+                                 const void* hbag_bf16, void* d_bag_bf16, float relu_gate, float* d_bias,
+                                 const mpo_bag_plan* plan /* nullable */, void* workspace, size_t workspace_bytes,
+                                 mpo_stream_t stream);
 
 /* ==== the 6 x d token tail.  Parameter and gradient tensors are passed as arrays of device pointers in
  * the order listed per entry (the reference's state_dict order); dropout streams are counters of a counter-based generator (masks = a pure function of seed and counter)

@@ -51,6 +51,9 @@ _SIGNATURES = {
                                              _P, _P]),
     "mpo_pack_patch_weight": (c_int, [_P, _P, c_int, c_int, _P]),
     "mpo_patch_fc_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mpo_patch_fc_f32_workspace_bytes": (c_size_t, [c_int]),
+    "mpo_patch_fc_f32_forward": (c_int, [_P, ctypes.c_int64, c_int, _P, _P, c_int, c_float, c_uint64, c_uint64, _P, _P, _P, c_size_t, _P]),
+    "mpo_patch_fc_f32_backward": (c_int, [_P, _P, _P, ctypes.c_int64, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "mpo_patch_fc_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, c_uint64, c_uint64, _P, _P, _P,
                                      _P, c_size_t, _P]),
     "mpo_coattn_mcat_backward": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
@@ -70,6 +73,8 @@ _SIGNATURES = {
                                             c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P,
                                             _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_nacagat_patch_grad": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_size_t, _P]),
+    "mpo_nacagat_patch_grad_fused": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
+                                             c_size_t, _P]),
     "mpo_survival_head_forward": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "mpo_survival_head_backward": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "mpo_ces_loss_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P]),
@@ -98,6 +103,7 @@ _SIGNATURES = {
     "mpo_fusion_head_loss_backward": (c_int, [_P] + [c_int] * 5 + [_P, _P, _P, _P] + [_P, c_size_t, _P]),
     "mpo_step_counters_bump": (c_int, [_P, _P, _P]),
     "mpo_set_gemm_fast_path": (c_int, [c_int]),
+    "mpo_set_coattn_bwd_two_wave": (c_int, [c_int]),
     "mpo_omic_snn_saved_floats": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_workspace_bytes": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_rng_span": (c_uint64, [c_int] * 3),

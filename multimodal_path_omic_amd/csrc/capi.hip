@@ -79,7 +79,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 10; }
+int mpo_abi_version(void) { return 11; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -232,6 +232,32 @@ int mpo_patch_fc_forward(const void* patches, const int32_t* cu_rows, int n_slid
     if ((rc = mpo_launch_pack_patch_weight(patch_weight, w_bf16, embed, patch_dim, stream))) return rc;
     return mpo_launch_patch_coattn_fwd(patches, w_bf16, patch_bias, cu_rows, nullptr, h_bag, nullptr, nullptr, nullptr, 0, drop_p,
                                        seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), plan, stream);
+}
+
+// fp32-stored window: the patch layer on patch_fc_f32.hip
+size_t mpo_patch_fc_f32_workspace_bytes(int backward) {
+    return 256 + 4 * (backward ? mpo_patch_wgrad_f32_workspace_floats() : mpo_patch_fc_f32_workspace_floats());
+}
+int mpo_patch_fc_f32_forward(const float* patches, int64_t total_rows, int patch_dim, const float* patch_weight,
+                             const float* patch_bias, int embed, float drop_p, uint64_t seed, uint64_t offset,
+                             const uint64_t* rng_epoch, float* h_bag, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    MPO_CHECK(patches && patch_weight && patch_bias && h_bag, "fp32 patch layer: null operand");
+    MPO_CHECK(total_rows >= 1, "fp32 patch layer: total_rows %lld", (long long)total_rows);
+    Arena ws(workspace, workspace_bytes);
+    float* wpk = ws.floats(mpo_patch_fc_f32_workspace_floats());
+    MPO_CHECK(wpk, "fp32 patch layer: workspace too small (%zu bytes)", workspace_bytes);
+    return mpo_launch_patch_fc_f32(patches, patch_weight, patch_bias, h_bag, total_rows, embed, patch_dim, drop_p, seed, offset,
+                                   reinterpret_cast<const unsigned long long*>(rng_epoch), wpk, stream);
+}
+int mpo_patch_fc_f32_backward(const float* d_h_bag, const float* h_bag, const float* patches, int64_t total_rows, int embed,
+                              int patch_dim, float gate, float* d_weight, float* d_bias, void* workspace, size_t workspace_bytes,
+                              mpo_stream_t stream) {
+    MPO_CHECK(d_h_bag && patches && d_weight, "fp32 patch layer backward: null operand");
+    MPO_CHECK(total_rows >= 1, "fp32 patch layer backward: total_rows %lld", (long long)total_rows);
+    Arena ws(workspace, workspace_bytes);
+    float* part = ws.floats(mpo_patch_wgrad_f32_workspace_floats());
+    MPO_CHECK(part, "fp32 patch layer backward: workspace too small (%zu bytes)", workspace_bytes);
+    return mpo_launch_patch_wgrad_f32(d_h_bag, h_bag, patches, total_rows, embed, patch_dim, gate, d_weight, d_bias, part, stream);
 }
 
 // the fused bag pass alone (bench.py's roofline leg, profiling workloads)
@@ -486,6 +512,28 @@ int mpo_nacagat_patch_grad(const int32_t* cu_rows, int n_slides, int total_rows,
     return 0;
 }
 
+int mpo_nacagat_patch_grad_fused(const int32_t* cu_rows, int n_slides, int total_rows, int max_rows, int n_q, int embed,
+                                 const float* attn_map, const float* d_ctx, const void* d_kbag_bf16, const float* w_k,
+                                 const void* hbag_bf16, void* d_bag_bf16, float relu_gate, float* d_bias,
+                                 const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+    if (int rc = check_common(MPO_BF16, n_slides, total_rows, max_rows, n_q, embed)) return rc;
+    MPO_CHECK(attn_map && d_ctx && d_kbag_bf16 && w_k && hbag_bf16 && d_bag_bf16, "nacagat patch grad: null operand");
+    MPO_CHECK(d_bag_bf16 != d_kbag_bf16, "nacagat patch grad (fused): d_bag must not alias d_kbag");
+    MPO_CHECK(((reinterpret_cast<uintptr_t>(d_kbag_bf16) | reinterpret_cast<uintptr_t>(hbag_bf16) |
+                reinterpret_cast<uintptr_t>(d_bag_bf16)) & 15) == 0, "nacagat patch grad: bag operands must be 16-byte aligned");
+    const BagPlan splits = make_plan(plan_, n_slides, max_rows);
+    if (int rc = check_plan(splits, n_slides)) return rc;
+    Arena ws(workspace, workspace_bytes);
+    float* part_cs = d_bias ? ws.floats(plan_parts(splits) * embed) : nullptr;
+    MPO_CHECK(part_cs || !d_bias, "nacagat patch grad: workspace too small (%zu bytes)", workspace_bytes);
+    int rc;
+    if ((rc = mpo_launch_k2_patch_grad(cu_rows, d_kbag_bf16, w_k, attn_map, d_ctx, hbag_bf16, d_bag_bf16, relu_gate, part_cs, n_q,
+                                       embed, splits, stream))) return rc;
+    if (d_bias)
+        if ((rc = mpo_launch_colsum(part_cs, d_bias, (int)plan_parts(splits), embed, embed, 0, stream))) return rc;
+    return 0;
+}
+
 int mpo_coattn_fwd_bagpass(const void* bag, int bag_dtype, const int32_t* cu_rows, int n_slides, int embed,
                            const float* qk2, float* part_ml, float* part_ctx, float* raw_logits, int n_q, int max_rows,
                            const mpo_bag_plan* plan_, mpo_stream_t stream) {
@@ -577,6 +625,7 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
 // Verification hook: the small-row GEMMs have a branch-free body for regular products and a general body; both must
 // give the same bits.  enabled = 0 routes every product through the general body.  Returns the previous setting.
 int mpo_set_gemm_fast_path(int enabled) { return mpo_gemm_fast_path(enabled); }
+int mpo_set_coattn_bwd_two_wave(int enabled) { return mpo_coattn_bwd8_enable(enabled); }
 
 // The two device-resident per-step counters of a captured training step, bumped by one launch.
 int mpo_step_counters_bump(uint64_t* rng_epoch, int32_t* adam_step, mpo_stream_t stream) {

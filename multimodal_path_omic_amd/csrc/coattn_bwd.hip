@@ -543,6 +543,8 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
     (void)a_map;
     MPO_CHECK(relu_gate == 0.f || !bag_f32, "coattn backward: the fused relu/dropout gate needs a bf16 bag");
     MPO_CHECK(delta || ctx, "coattn backward: delta or ctx");
+    if (mpo_coattn_bwd8_covers(bag_f32, embed, n_q, da_map))
+        return mpo_launch_coattn_bwd8(bag, cu, qk2, lse2, dctx, delta, ctx, dbag, part_dqk, part_colsum, n_q, plan, relu_gate, stream);
     dim3 grid = plan_grid(plan);
 #define MPO_BWD_CASE(EV)                                                                                     \
     case EV:                                                                                                 \

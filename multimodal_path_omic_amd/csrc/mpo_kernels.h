@@ -156,6 +156,25 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
                           const float* ctx, const float* a_map, const float* da_map,
                           void* dbag, float* part_dqk, float* part_colsum /* nullable [parts][E] */, int n_q, const BagPlan& plan,
                           float relu_gate, hipStream_t stream);
+// the same pass for a bf16 bag at embed 256, <= 8 queries, no map gradient, two waves per SIMD (coattn_bwd8.hip);
+// mpo_launch_coattn_bwd routes to it when mpo_coattn_bwd8_covers()
+bool mpo_coattn_bwd8_covers(int bag_f32, int embed, int n_q, const float* da_map);
+int mpo_coattn_bwd8_enable(int enabled);   // returns the previous setting
+int mpo_launch_coattn_bwd8(const void* bag, const int* cu, const float* qk2, const float* lse2, const float* dctx,
+                           const float* delta, const float* ctx, void* dbag, float* part_dqk, float* part_colsum, int n_q,
+                           const BagPlan& plan, float relu_gate, hipStream_t stream);
+// fp32-stored window: the patch layer as three-term bf16 products (patch_fc_f32.hip); ws = the *_workspace_floats() below
+size_t mpo_patch_fc_f32_workspace_floats();
+size_t mpo_patch_wgrad_f32_workspace_floats();
+int mpo_launch_patch_fc_f32(const float* x, const float* w, const float* bias, float* h, long long total_rows, int embed,
+                            int patch_dim, float drop_p, unsigned long long seed, unsigned long long offset,
+                            const unsigned long long* epoch, float* ws, hipStream_t stream);
+int mpo_launch_patch_wgrad_f32(const float* dh, const float* hbag, const float* x, long long total_rows, int embed, int patch_dim,
+                               float gate, float* d_weight, float* d_bias, float* ws, hipStream_t stream);
+// K2's patch-side gradient with the product back through the key projection inside the pass (k2_patchgrad.hip)
+int mpo_launch_k2_patch_grad(const int* cu, const void* dk_bf16, const float* w_k, const float* amap, const float* dctx,
+                             const void* hbag_bf16, void* out_bf16, float gate, float* part_colsum, int n_q, int embed,
+                             const BagPlan& plan, hipStream_t stream);
 int mpo_gemm_fast_path(int enabled);   // gemm_f32.hip: returns the previous setting
 // dW_H = g^T X of the patch layer, hand-written (patch_wgrad.hip): part = mpo_patch_wgrad_partial_floats() floats
 size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim);

@@ -71,7 +71,9 @@ class _FusionModelBase(nn.Module):
         p = self.H[2].p if self.training else 0.0
         if x.dtype == torch.bfloat16:
             h = ops.patch_fc(x, lin.weight, lin.bias, p, pre_gated_grad=self._fused_bag_gate, batch=bags)
-        else:
+        elif ops.patch_fc_f32_supported(x, lin.weight):
+            h = ops.patch_fc_f32(x, lin.weight, lin.bias, p)        # fp32 window, 1024 -> 256: hand-written both ways
+        else:                                                       # fp32 window of the small / big models: library GEMM
             h = F.dropout(torch.relu(F.linear(x.float(), lin.weight, lin.bias)), p, self.training)
         return bags.with_data(h)
 

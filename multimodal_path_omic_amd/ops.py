@@ -15,6 +15,11 @@ import torch
 from . import _lib as L
 
 
+# Upper bound on the workgroups of a window's work plan (None: one per CU).  A measurement knob (tools/gpu_probe_overlap.py):
+# persistent bag kernels on fewer CUs leave the rest to whatever another stream launches.
+plan_workgroups = None
+
+
 @dataclass
 class BagBatch:
     """A window of slides' bags concatenated along rows ("ragged").
@@ -41,6 +46,8 @@ class BagBatch:
         with the batch; returns a ctypes pointer for the C ABI."""
         if self._plan is None:
             target = L.lib().mpo_coattn_target_workgroups()
+            if plan_workgroups is not None:             # (fewer row ranges than CUs: leaves CUs to kernels of another stream)
+                target = max(len(self.lengths), min(target, int(plan_workgroups)))
             rpw = -(-self.total_rows // target)
             rpw = max(32, -(-rpw // 32) * 32)
             # every slide rounds its workgroup count up: grow the range until the WHOLE window fits one workgroup per CU
@@ -410,6 +417,48 @@ def patch_weight_grad(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> to
     return _splitk_tn(g, x, out)
 
 
+class PatchFcF32Fn(torch.autograd.Function):
+    """H_bag = dropout_p(relu(X W_H^T + b)) for an fp32-stored window through Linear(1024, 256) (models/mcat/mcat.py:24-29,87),
+    hand-written both ways (csrc/patch_fc_f32.hip): products as three bf16 MFMA terms of hi / lo operand splits (fp32
+    accumulation, ~4e-6 absolute on H_bag), dropout mask kept in H_bag as zeros; backward = ONE pass that applies the
+    ReLU / dropout derivative read off H_bag to the incoming gradient and forms dW_H = g^T X and db_H = colsum(g)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, drop_p: float):
+        lib = L.lib()
+        h = torch.empty(x.shape[0], weight.shape[0], device=x.device, dtype=torch.float32)
+        seed, off = _reserve(h.numel() // 16 + 2) if drop_p > 0 else (0, 0)
+        ws = _workspace(lib.mpo_patch_fc_f32_workspace_bytes(0), x.device)
+        L.check(lib.mpo_patch_fc_f32_forward(L.ptr(x), x.shape[0], x.shape[1], L.ptr(weight), L.ptr(bias), weight.shape[0],
+                                             float(drop_p), seed, off, _epoch(), L.ptr(h), L.ptr(ws), ws.numel(), L.stream_of(x)),
+                "mpo_patch_fc_f32_forward")
+        ctx.save_for_backward(x, h)
+        ctx.param_refs = (weight, bias)
+        ctx.gate = 1.0 / (1.0 - _realised_drop(drop_p)) if drop_p > 0 else 1.0
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = L.lib()
+        x, h = ctx.saved_tensors
+        dh = dh.contiguous()
+        dw, db = (grad_out(p) for p in ctx.param_refs)
+        ws = _workspace(lib.mpo_patch_fc_f32_workspace_bytes(1), x.device)
+        L.check(lib.mpo_patch_fc_f32_backward(L.ptr(dh), L.ptr(h), L.ptr(x), x.shape[0], h.shape[1], x.shape[1], ctx.gate, L.ptr(dw),
+                                              L.ptr(db), L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_patch_fc_f32_backward")
+        return None, dw, db, None
+
+
+def patch_fc_f32_supported(x, weight) -> bool:
+    """mpo_patch_fc_f32_*: an fp32 window through Linear(1024, 256)."""
+    return x.dtype == torch.float32 and x.is_contiguous() and tuple(weight.shape) == (256, 1024)
+
+
+def patch_fc_f32(x, weight, bias, drop_p: float):
+    """H_bag = dropout(relu(x W^T + b)) in fp32 storage on the hand-written kernels (no library GEMM)."""
+    return PatchFcF32Fn.apply(x, weight, bias, float(drop_p))
+
+
 # ------------------------------------------------------------------------------------ row f1: patch layer + K1 in one pass
 class PatchCoAttnMCATFn(torch.autograd.Function):
     """H_bag = dropout_p(relu(X W_H^T + b_H)) AND MCAT's co-attention over it (models/mcat/mcat.py:24-29,87,97) with ONE
@@ -733,9 +782,9 @@ def bag_self_attention(x, mha, training: bool, need_weights: bool = True):
     if need_weights and mha.num_heads != 1:
         raise NotImplementedError("bag self-attention: the M x M map is returned for one head (models/ge_nacagat/ge_nacagat.py:27)")
     xb = x if x.dim() == 3 else x.unsqueeze(0)
-    qkv = F.linear(xb.float(), mha.in_proj_weight, mha.in_proj_bias)
+    qkv = linear(xb.float(), mha.in_proj_weight, mha.in_proj_bias)          # the many-row fp32 MFMA GEMM (gemm_f32_rows.hip)
     out, amap = BagSelfAttentionFn.apply(qkv, mha.num_heads, mha.dropout if training else 0.0, bool(need_weights))
-    out = F.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    out = linear(out, mha.out_proj.weight, mha.out_proj.bias)
     if x.dim() == 2:
         out, amap = out[0], (amap[0] if amap is not None else None)
     return out, amap
@@ -1127,7 +1176,10 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
             L.check(lib.mpo_key_projection(L.ptr(bag_data), T, E, L.ptr(w_k), L.ptr(b_k), L.ptr(kbag), L.stream_of(query)),
                     "mpo_key_projection")
         else:
-            kbag = F.linear(bag_data.float(), in_w[E:2 * E], in_b[E:2 * E])
+            # fp32 bag (or the small model's bf16 bag): the exact-fp32 MFMA GEMM of the token tail in its many-row form
+            kbag = torch.empty(T, E, device=dev, dtype=torch.float32)
+            L.check(lib.mpo_linear_forward(L.ptr(bag_data.float().contiguous()), L.ptr(in_w[E:2 * E]), L.ptr(in_b[E:2 * E]), L.ptr(kbag),
+                                           T, E, E, 1.0, L.ACT["none"], L.stream_of(query)), "mpo_linear_forward")
         q_proj = torch.empty(R, E, device=dev, dtype=torch.float32)
         out = torch.empty(R, E, device=dev, dtype=torch.float32)
         amap = torch.empty(n_q * T, device=dev, dtype=torch.float32)
@@ -1177,18 +1229,29 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         # bf16 GEMM (0.59 ms in fp32).
         w_k = in_w[E:2 * E]
         if fused_patch:
-            d_h = torch.mm(d_k, w_k.to(torch.bfloat16))
             gate = ctx.bag_relu_gate
             colsum = _bias_grad_slot(ctx.bag_bias, E, dev) if gate != 0.0 else None
-            L.check(lib.mpo_nacagat_patch_grad(L.ptr(batch.cu), batch.n_slides, T, batch.max_rows, n_q, E, L.ptr(amap), L.ptr(d_ctx),
-                                               L.ptr(d_h), L.ptr(bag_data), L.ptr(d_h), gate, L.ptr(colsum), batch.plan(),
-                                               L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_nacagat_patch_grad")
+            if E == 256:
+                # dH = (dK W_k + A_drop^T dctx) (.) gate in ONE hand-written pass (no library GEMM): csrc/k2_patchgrad.hip
+                d_h = torch.empty_like(d_k)
+                L.check(lib.mpo_nacagat_patch_grad_fused(L.ptr(batch.cu), batch.n_slides, T, batch.max_rows, n_q, E, L.ptr(amap),
+                                                         L.ptr(d_ctx), L.ptr(d_k), L.ptr(w_k), L.ptr(bag_data), L.ptr(d_h), gate,
+                                                         L.ptr(colsum), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)),
+                        "mpo_nacagat_patch_grad_fused")
+            else:                                  # the small model (E = 128): library GEMM, then the one-pass epilogue
+                d_h = torch.mm(d_k, w_k.to(torch.bfloat16))
+                L.check(lib.mpo_nacagat_patch_grad(L.ptr(batch.cu), batch.n_slides, T, batch.max_rows, n_q, E, L.ptr(amap),
+                                                   L.ptr(d_ctx), L.ptr(d_h), L.ptr(bag_data), L.ptr(d_h), gate, L.ptr(colsum),
+                                                   batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_nacagat_patch_grad")
             if colsum is not None:
                 d_h._mpo_colsum = colsum          # the producing layer's bias gradient (PatchFcFn.backward picks it up)
             patch_weight_grad(d_k, bag_data, d_in_w[E:2 * E])     # dW_k = d_k^T H_bag (hand-written for 256 x 256, bf16)
         else:
-            d_h.addmm_(d_k, w_k)
-            torch.mm(d_k.t(), bag_data, out=d_in_w[E:2 * E])
+            # fp32 bag: d_h += d_k W_k and dW_k = d_k^T H on the fp32 MFMA GEMMs (many-row / long-K forms)
+            s_ = L.stream_of(query)
+            L.check(lib.mpo_linear_backward_input(L.ptr(d_k), L.ptr(w_k), L.ptr(d_h), T, E, E, 1.0, 1, s_), "mpo_linear_backward_input")
+            L.check(lib.mpo_linear_backward_weight(L.ptr(d_k), L.ptr(bag_data), L.ptr(d_in_w[E:2 * E]), None, T, E, E, 1.0, s_),
+                    "mpo_linear_backward_weight")
         # (d_in_b[E:2E], the key bias gradient = column sums of d_k, came out of the kernel that wrote d_k)
         return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None
 

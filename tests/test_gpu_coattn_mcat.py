@@ -194,3 +194,60 @@ def test_full_slide_100k_patches_fp32(dev, kind):
     gs = torch.autograd.grad((out * p_out.to(dev)).sum() + 1e3 * (a * p_a.to(dev)).sum(), tensors)
     for (n, _), gr in zip(named, gs):
         assert relerr(gr, g_o[n]) < 3e-3, (n, relerr(gr, g_o[n]))
+
+
+@pytest.mark.parametrize("n_q", [1, 6, 8])
+@pytest.mark.parametrize("gate", [0.0, 4.0 / 3.0])
+def test_two_wave_backward_equals_the_general_kernel(dev, n_q, gate):
+    """K1's backward bag pass for a bf16 bag at embed 256 / <= 8 queries runs on csrc/coattn_bwd8.hip (two waves per SIMD,
+    operands in LDS, both MFMA orientations in one pass, 16-byte dH stores); every other geometry on the general kernel.  Same
+    mathematics: on a ragged window whose bags straddle every tile / workgroup edge the two must agree to the rounding both
+    share -- the dH product takes its Z^T = [dctx | qk] operand as ONE bf16 term in both (2^-9 per term; the two-wave kernel
+    rounds Z x gate, the general one Z), and d_bag is emitted in bf16 -- and to fp32 summation order elsewhere; with the
+    patch layer's ReLU/dropout gate fused (zeros of the bag switch the gradient off, column sums = bias gradient) and
+    without.  (Each kernel is held to the oracle separately by test_coattn_forward_backward and the model tests.)"""
+    from multimodal_path_omic_amd import _lib as L
+    from multimodal_path_omic_amd import ops
+    lengths = [1, 31, 32, 33, 255, 700, 3000, 5000]
+    g = syn.rng(77 + n_q)
+    sd = syn.fill_state_dict(C.MCAT_COATTN_SHAPES, 78)
+    p = {k[len("co_attention."):]: v.to(dev) for k, v in sd.items()}
+    bags = [torch.relu(syn.normal(g, (m, C.E))).to(dev).to(torch.bfloat16) for m in lengths]
+    query = syn.normal(g, (len(lengths) * n_q, C.E)).to(dev)
+    probe = syn.normal(g, (len(lengths) * n_q, C.E)).to(dev)
+    from multimodal_path_omic_amd.dp import FlatGradBucket
+    bias = torch.nn.Parameter(torch.zeros(C.E, device=dev))           # stands in for the patch layer's bias (colsum receiver)
+    bucket = FlatGradBucket([bias])                                   # the kernel writes the column sums into its slice
+
+    def run(two_wave):
+        prev = L.lib().mpo_set_coattn_bwd_two_wave(int(two_wave))
+        try:
+            batch = BagBatch.from_list(bags)
+            data = batch.data.detach().requires_grad_(True)
+            bucket.begin()
+            bucket.flat.fill_(float("nan"))
+            if gate:
+                data._mpo_bias_param = bias
+            q = query.clone().requires_grad_(True)
+            w = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            out, _ = ops.coattn_mcat(q, batch.with_data(data), w["in_proj_weight"], w["in_proj_bias"], w["out_proj.weight"],
+                                     w["out_proj.bias"], False, gate)
+            (out * probe).sum().backward()
+            cs = bucket.flat[:C.E].clone() if gate else None
+            return data.grad.float(), q.grad, {k: v.grad for k, v in w.items()}, cs
+        finally:
+            L.lib().mpo_set_coattn_bwd_two_wave(prev)
+    db8, dq8, dw8, cs8 = run(True)
+    db1, dq1, dw1, cs1 = run(False)
+    scale = float(db1.abs().max())
+    assert float((db8 - db1).abs().max()) < 1e-2 * scale
+    assert float((db8 - db1).abs().mean()) < 5e-3 * float(db1.abs().mean())
+    if gate:
+        zero = torch.cat(bags).float() == 0
+        assert float(db8[zero].abs().max()) == 0.0                    # the gate switches the gradient off where H = 0
+        assert relerr(cs8, cs1) < 1e-3
+        assert relerr(cs8, db8.sum(0)) < 1e-4                        # column sums of the rows it wrote
+    assert relerr(dq8, dq1) < 1e-4
+    for k in dw1:
+        if dw1[k] is not None:
+            assert relerr(dw8[k], dw1[k]) < 1e-4 or float(dw1[k].abs().max()) < 1e-12, k

@@ -9,6 +9,8 @@ from multimodal_path_omic_amd import synthetic as syn
 from multimodal_path_omic_amd.blocks import ContextualAttentionGate, PreGatingContextualAttention
 from oracle import mpo_oracle as O
 
+from multimodal_path_omic_amd.ops import make_cu as ops_make_cu
+
 pytestmark = pytest.mark.gpu
 # gradient bars = about twice the measured worst case (printed per case, pytest -rA)
 GRAD_TOL_PEAKY = 1e-2
@@ -197,3 +199,58 @@ def test_patch_grad_one_pass(dev, lengths, gate, E):
     assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
     cs_ref = got.sum(0)                                                         # sums of what was written
     assert float((colsum.double().cpu() - cs_ref).abs().max()) <= 1e-4 * max(1.0, float(cs_ref.abs().max()))
+
+
+@pytest.mark.parametrize("lengths", [[1, 31, 32, 33, 64, 700, 2999, 4000], [20000, 9000, 77], [24000], [15000] * 6],
+                         ids=["one_tile_per_wg", "four_tiles", "three_tiles", "eleven_tiles"])
+@pytest.mark.parametrize("n_q", [1, 6, 16])
+@pytest.mark.parametrize("gate", [0.0, 1.0, 4.0 / 3.0])
+def test_fused_patch_side_gradient_matches_torch(dev, n_q, gate, lengths):
+    """mpo_nacagat_patch_grad_fused (csrc/k2_patchgrad.hip): d_bag = (dK W_k + A_drop^T dctx) (.) [H > 0] gate in one pass, with
+    the product back through the key projection on the MFMA inside the kernel (it used to be a library GEMM followed by a
+    second pass).  Against torch fp32 on the same bf16 operands, over a ragged window whose slides straddle tile and
+    workgroup edges; column sums = what the caller would sum from the emitted bf16 rows."""
+    from multimodal_path_omic_amd import _lib as L
+    from multimodal_path_omic_amd.ops import BagBatch
+    E, T = 256, sum(lengths)
+    gen = torch.Generator(device=dev).manual_seed(100 + n_q)
+    h = torch.relu(torch.randn(T, E, device=dev, generator=gen)).to(torch.bfloat16)
+    dk = (torch.randn(T, E, device=dev, generator=gen) * 0.1).to(torch.bfloat16)
+    w_k = (torch.rand(E, E, device=dev, generator=gen) - 0.5) / 8
+    dctx = torch.randn(len(lengths) * n_q, E, device=dev, generator=gen)
+    batch = BagBatch(h, ops_make_cu(lengths, dev), lengths)
+    amap = torch.rand(n_q * T, device=dev, generator=gen) / 100
+    out = torch.full((T, E), float("nan"), device=dev, dtype=torch.bfloat16)
+    colsum = torch.empty(E, device=dev)
+    lib = L.lib()
+    ws = torch.empty(lib.mpo_nacagat_workspace_bytes(len(lengths), n_q, E, max(lengths), T), dtype=torch.uint8, device=dev)
+    L.check(lib.mpo_nacagat_patch_grad_fused(L.ptr(batch.cu), len(lengths), T, max(lengths), n_q, E, L.ptr(amap), L.ptr(dctx),
+                                             L.ptr(dk), L.ptr(w_k), L.ptr(h), L.ptr(out), gate, L.ptr(colsum), batch.plan(),
+                                             L.ptr(ws), ws.numel(), L.stream_of(h)), "mpo_nacagat_patch_grad_fused")
+    ref = dk.float() @ w_k.to(torch.bfloat16).float()
+    off = 0
+    for b, m in enumerate(lengths):
+        a_b = amap[n_q * off:n_q * (off + m)].view(n_q, m)
+        ref[off:off + m] += a_b.t() @ dctx[b * n_q:(b + 1) * n_q]
+        off += m
+    if gate != 0.0:
+        ref = ref * (h.float() > 0) * gate
+    err = (out.float() - ref).abs()
+    assert not torch.isnan(out.float()).any()
+    assert float((err - 2.0 ** -7 * ref.abs()).max()) < 2e-3 * float(ref.abs().max())     # bf16 output: one ulp + fp32 noise
+    assert float(err.mean()) < 2e-3 * float(ref.abs().mean())
+    if gate != 0.0:
+        assert float(out.float()[h.float() == 0].abs().max()) == 0.0
+    torch.testing.assert_close(colsum, out.float().sum(0), rtol=1e-4, atol=1e-3)
+    # a window is the concatenation of its slides: the same rows alone (a one-slide plan: other row ranges, other tile counts
+    # per workgroup) must come out bit for bit
+    off = 0
+    for b, m in enumerate(lengths[:3]):
+        one = BagBatch(h[off:off + m], ops_make_cu([m], dev), [m])
+        out1 = torch.full((m, E), float("nan"), device=dev, dtype=torch.bfloat16)
+        a_b = amap[n_q * off:n_q * (off + m)].contiguous()
+        L.check(lib.mpo_nacagat_patch_grad_fused(L.ptr(one.cu), 1, m, m, n_q, E, L.ptr(a_b), L.ptr(dctx[b * n_q:(b + 1) * n_q].contiguous()),
+                                                 L.ptr(dk[off:off + m]), L.ptr(w_k), L.ptr(h[off:off + m]), L.ptr(out1), gate, None,
+                                                 one.plan(), L.ptr(ws), ws.numel(), L.stream_of(h)), "mpo_nacagat_patch_grad_fused")
+        assert torch.equal(out1, out[off:off + m]), (b, m)
+        off += m
