@@ -1150,6 +1150,11 @@ def next_dropout_stream(n_elements: int):
     return seed, offset
 
 
+# False: the patch-side gradient of K2 as library GEMM + mpo_nacagat_patch_grad (the r02 path; kept for the small model and as
+# the cross-check of csrc/k2_patchgrad.hip in tools/gpu_diag_nacagat.py)
+k2_fused_patch_grad = True
+
+
 class CoAttnNaCAGaTFn(torch.autograd.Function):
     """NaCAGaT narrow-gated attention core over a ragged window (models/blocks.py:114-206).
     Returns (q_proj, attn_out, post-dropout map).  K = H W_k^T + b_k is a plain GEMM done here with
@@ -1231,7 +1236,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         if fused_patch:
             gate = ctx.bag_relu_gate
             colsum = _bias_grad_slot(ctx.bag_bias, E, dev) if gate != 0.0 else None
-            if E == 256:
+            if E == 256 and k2_fused_patch_grad:
                 # dH = (dK W_k + A_drop^T dctx) (.) gate in ONE hand-written pass (no library GEMM): csrc/k2_patchgrad.hip
                 d_h = torch.empty_like(d_k)
                 L.check(lib.mpo_nacagat_patch_grad_fused(L.ptr(batch.cu), batch.n_slides, T, batch.max_rows, n_q, E, L.ptr(amap),

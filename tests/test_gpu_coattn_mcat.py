@@ -245,7 +245,7 @@ def test_two_wave_backward_equals_the_general_kernel(dev, n_q, gate):
     if gate:
         zero = torch.cat(bags).float() == 0
         assert float(db8[zero].abs().max()) == 0.0                    # the gate switches the gradient off where H = 0
-        assert relerr(cs8, cs1) < 1e-3
+        assert relerr(cs8, cs1) < 2e-2                               # (sums of thousands of signed bf16 values that differ in the last place)
         assert relerr(cs8, db8.sum(0)) < 1e-4                        # column sums of the rows it wrote
     assert relerr(dq8, dq1) < 1e-4
     for k in dw1:

@@ -212,7 +212,13 @@ def test_full_size_bf16_training_window_equals_per_slide(dev, kind):
         (loss / n).backward()
     for k, p in model.named_parameters():
         scale = max(float(p.grad.abs().max()), 1e-3)
-        assert float((grads_w[k] - p.grad).abs().max()) / scale < 5e-4, k
+        # H.*: the patch layer's pre-activation gradient travels in bf16 and is heavy-tailed (median 4e-9 against a maximum 1e5
+        # times larger).  The two runs' fp32 tails differ in the last bit, so 0.1-0.3 % of the gradient's elements round to the
+        # other bf16 neighbour (measured, tools/gpu_diag_window_vs_slide.py); when one of the few dominant elements is among
+        # them a row of dW_H moves by up to one bf16 ulp of it, 2^-8 = 3.9e-3 (seen: 4.7e-4 with the r02 two-pass K2 gradient,
+        # 1.7e-3 with the one-pass kernel -- other elements flipped, same count).  Everything else is fp32 all the way.
+        bar = 5e-3 if k.startswith("H.") else 5e-4
+        assert float((grads_w[k] - p.grad).abs().max()) / scale < bar, k
 
 
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])
