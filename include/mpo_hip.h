@@ -221,6 +221,10 @@ int mpo_map_block_scale(const float* a_map, const float* scale, const int32_t* c
  * w_k = in_proj_weight + embed*embed, b_k = in_proj_bias + embed (nullable). */
 int mpo_key_projection(const void* hbag_bf16, int64_t rows, int embed, const float* w_k, const float* b_k, float* kbag,
                        mpo_stream_t stream);
+/* embed_dim 512 (model_size 'big', models/nacagat/nacagat.py:17-18; ABI v11): kbag, hbag, d_kbag and d_hbag of the two entries
+ * below are in the SPLIT-HALVES layout [2][total_rows][256] -- columns 0..255 of every row, then columns 256..511 -- and each
+ * bag pass runs once per half on the 256-wide kernels (maps are summed over the halves, column-indexed results sit side by
+ * side).  Query-side tensors ([n_slides*n_q, 512]) and parameters keep their natural layout.  embed 128 / 256: row-major. */
 size_t mpo_nacagat_saved_floats(int n_slides, int n_q, int embed);
 size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_rows, int total_rows);
 int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,

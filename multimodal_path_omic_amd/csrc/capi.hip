@@ -354,7 +354,21 @@ size_t mpo_nacagat_workspace_bytes(int n_slides, int n_q, int embed, int max_row
     b = arena_need(b, max_parts(n_slides) * embed);
     b = arena_need(b, (size_t)n_q * total_rows);
     b = arena_need(b, (size_t)n_q * total_rows);
+    if (embed == 512) {                                            // the column-half passes of the big model (see below)
+        for (int i = 0; i < 6; ++i) b = arena_need(b, R * (embed / 2));
+        b = arena_need(b, (size_t)2 * n_q * total_rows);
+    }
     return b + 256;
+}
+
+// embed_dim 512 ('big', models/nacagat/nacagat.py:17-18): the bag kernels are built for embed <= 256, so the two bags travel in
+// the SPLIT-HALVES layout [2][total_rows][256] (columns 0..255 | 256..511) and every bag pass runs once per column half on
+// the 256-wide kernels: the score / gradient maps are sums over the halves (linear in the embed index), the column-indexed
+// results (context, query-side sums, dK, dH) are the halves side by side.  The 6 x 512 query-side tensors keep their natural
+// layout; their halves are strided copies.  Functional, not tuned (four small copies and one map-sized add per pass).
+static int copy_cols(float* dst, size_t dst_ld, const float* src, size_t src_ld, int rows, int cols, hipStream_t s) {
+    MPO_HIP(hipMemcpy2DAsync(dst, dst_ld * 4, src, src_ld * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToDevice, s));
+    return 0;
 }
 
 int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, int bag_dtype, const int32_t* cu_rows, int n_slides,
@@ -365,15 +379,22 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
                                float* saved, const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes,
                                mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
-    MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
     MPO_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention dropout p must be in [0,1) (got %f)", (double)drop_p);
     MPO_CHECK(k_dtype == MPO_F32, "nacagat co-attention: K must be fp32 (k_dtype %d): the narrow gate amplifies key rounding", k_dtype);
     const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32;
+    const int NH = E == 512 ? 2 : 1, EH = E / NH;                          // column halves (split-halves bag layout at 512)
+    const size_t half_k = (size_t)total_rows * EH * 4, half_h = (size_t)total_rows * EH * (f32 ? 4 : 2);
     const BagPlan splits = make_plan(plan_, n_slides, max_rows);          // (named `splits`: it replaces the old count)
     if (int rc = check_plan(splits, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
     float* part = ws.floats(plan_parts(splits) * n_q * E);
     MPO_CHECK(part, "nacagat forward: workspace too small (%zu bytes)", workspace_bytes);
+    float *hq1 = nullptr, *hq2 = nullptr, *hctx = nullptr, *tmp_maps = nullptr;
+    if (NH > 1) {
+        hq1 = ws.floats((size_t)R * EH); hq2 = ws.floats((size_t)R * EH); hctx = ws.floats((size_t)R * EH);
+        tmp_maps = ws.floats((size_t)2 * n_q * total_rows);
+        MPO_CHECK(hq1 && hq2 && hctx && tmp_maps, "nacagat forward: workspace too small (%zu bytes)", workspace_bytes);
+    }
     float* qt = saved;
     float* qs2 = qt + (size_t)R * E;
     float* tq = qs2 + (size_t)R * E;
@@ -388,11 +409,29 @@ int mpo_coattn_nacagat_forward(const void* kbag, int k_dtype, const void* hbag, 
     if ((rc = mpo_linear_fwd(query, in_w, in_b, q_proj, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_launch_qprep(q_proj, qt, qs2, tq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
     // one pass over K: a = qs2 . K and g = tanh(q) . tanh(K)   (tanh(K) is never materialised)
-    if ((rc = mpo_launch_bag_rowdot_gated(kbag, 1, cu_rows, n_slides, E, qs2, tq, a_map, g_map, n_q, splits, stream))) return rc;
+    for (int h = 0; h < NH; ++h) {
+        const float *r1 = qs2, *r2 = tq;
+        if (NH > 1) {
+            if ((rc = copy_cols(hq1, EH, qs2 + h * EH, E, R, EH, stream))) return rc;
+            if ((rc = copy_cols(hq2, EH, tq + h * EH, E, R, EH, stream))) return rc;
+            r1 = hq1; r2 = hq2;
+        }
+        float* am = h == 0 ? a_map : tmp_maps;
+        float* gm = h == 0 ? g_map : tmp_maps + (size_t)n_q * total_rows;
+        if ((rc = mpo_launch_bag_rowdot_gated(static_cast<const char*>(kbag) + h * half_k, 1, cu_rows, n_slides, EH, r1, r2, am, gm,
+                                              n_q, splits, stream))) return rc;
+        if (h > 0)
+            if ((rc = mpo_launch_ew_add(score_maps, tmp_maps, (size_t)2 * n_q * total_rows, stream))) return rc;
+    }
     if ((rc = mpo_launch_gated_softmax_fwd(a_map, g_map, cu_rows, attn_map, lse2, asum, n_slides, n_q, drop_p, seed, offset,
                                            reinterpret_cast<const unsigned long long*>(rng_epoch), stream))) return rc;
-    if ((rc = mpo_launch_bag_colacc(hbag, f32, cu_rows, n_slides, E, attn_map, part, n_q, splits, stream))) return rc;
-    if ((rc = mpo_launch_coattn_bwd_reduce(part, ctx, n_slides, n_q, E, splits, stream))) return rc;
+    for (int h = 0; h < NH; ++h) {
+        if ((rc = mpo_launch_bag_colacc(static_cast<const char*>(hbag) + h * half_h, f32, cu_rows, n_slides, EH, attn_map, part, n_q,
+                                        splits, stream))) return rc;
+        if ((rc = mpo_launch_coattn_bwd_reduce(part, NH > 1 ? hctx : ctx, n_slides, n_q, EH, splits, stream))) return rc;
+        if (NH > 1)
+            if ((rc = copy_cols(ctx + h * EH, E, hctx, EH, R, EH, stream))) return rc;
+    }
     // attn = ctx W_v^T + (sum_m A_drop) b_v ;  out = attn W_o^T + b_o
     if ((rc = mpo_linear_fwd(ctx, in_w + (size_t)2 * E * E, nullptr, attn, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_launch_row_scaled_bias(attn, asum, in_b + 2 * E, R, E, stream))) return rc;
@@ -410,10 +449,12 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                 float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
                                 const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
-    MPO_CHECK(embed != 512, "nacagat co-attention: embed_dim 512 ('big') is not built yet");
     MPO_CHECK(k_dtype == MPO_F32, "nacagat co-attention: K must be fp32 (k_dtype %d): the narrow gate amplifies key rounding", k_dtype);
     MPO_CHECK(dk_dtype == MPO_F32 || dk_dtype == MPO_BF16, "d_kbag dtype %d is neither MPO_F32 nor MPO_BF16", dk_dtype);
     const int E = embed, R = n_slides * n_q, f32 = bag_dtype == MPO_F32;
+    const int NH = E == 512 ? 2 : 1, EH = E / NH;                          // column halves (split-halves bag layout at 512)
+    const size_t half_k = (size_t)total_rows * EH * 4, half_h = (size_t)total_rows * EH * (f32 ? 4 : 2);
+    const size_t half_dk = (size_t)total_rows * EH * (dk_dtype == MPO_F32 ? 4 : 2);
     const BagPlan splits = make_plan(plan_, n_slides, max_rows);
     if (int rc = check_plan(splits, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
@@ -434,6 +475,13 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     float* dg_map = ws.floats((size_t)n_q * total_rows);
     MPO_CHECK(dattn && dctx_ws && dqt && dtq && dq && spare && dasum && part && part2 && ds1_map && dg_map,
               "nacagat backward: workspace too small (%zu bytes)", workspace_bytes);
+    float* hb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [R][EH] scratch of the column-half passes
+    float* tmp_map = nullptr;
+    if (NH > 1) {
+        for (int i = 0; i < 6; ++i) hb[i] = ws.floats((size_t)R * EH);
+        tmp_map = ws.floats((size_t)2 * n_q * total_rows);
+        MPO_CHECK(hb[5] && tmp_map, "nacagat backward: workspace too small (%zu bytes)", workspace_bytes);
+    }
     const float* qt = saved;
     const float* qs2 = qt + (size_t)R * E;
     const float* tq = qs2 + (size_t)R * E;
@@ -459,35 +507,62 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                     mpo_args_bwd_weight(dattn, ctx, d_in_w + (size_t)2 * E * E, nullptr, R, E, E, 1.0f),
                                     &dbv, &das))) return rc;
     }
-    // map side
-    if ((rc = mpo_launch_bag_rowdot(hbag, f32, cu_rows, n_slides, E, dctx, ds1_map, 1.0f, n_q, splits, stream))) return rc;
+    // map side: dA = dctx . H^T (summed over the column halves at 512; hb[0], hb[1] keep the two halves of dctx)
+    for (int h = 0; h < NH; ++h) {
+        const float* dch = dctx;
+        if (NH > 1) {
+            if ((rc = copy_cols(hb[h], EH, dctx + h * EH, E, R, EH, stream))) return rc;
+            dch = hb[h];
+        }
+        if ((rc = mpo_launch_bag_rowdot(static_cast<const char*>(hbag) + h * half_h, f32, cu_rows, n_slides, EH, dch,
+                                        h == 0 ? ds1_map : tmp_map, 1.0f, n_q, splits, stream))) return rc;
+        if (h > 0)
+            if ((rc = mpo_launch_ew_add(ds1_map, tmp_map, (size_t)n_q * total_rows, stream))) return rc;
+    }
     if ((rc = mpo_launch_gated_softmax_bwd(a_map, g_map, cu_rows, lse2, dasum, d_attn_map, ds1_map, dg_map, n_slides, n_q,
                                            drop_p, seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), stream))) return rc;
     // query side: dq~ = ds1 K, dtq = dg TK
     // (one pass over K, tanh on the fly)
-    if ((rc = mpo_launch_bag_colacc_gated(kbag, 1, cu_rows, n_slides, E, ds1_map, dg_map, part, part2, n_q, splits, stream))) return rc;
-    {
+    for (int h = 0; h < NH; ++h) {
+        if ((rc = mpo_launch_bag_colacc_gated(static_cast<const char*>(kbag) + h * half_k, 1, cu_rows, n_slides, EH, ds1_map, dg_map,
+                                              part, part2, n_q, splits, stream))) return rc;
         BagFinish f{};
-        f.part[0] = part; f.out[0] = dqt; f.part[1] = part2; f.out[1] = dtq; f.n_red = 2;
-        if ((rc = mpo_launch_bag_finish(f, n_slides, n_q, E, splits, stream))) return rc;
+        f.part[0] = part; f.out[0] = NH > 1 ? hb[2] : dqt; f.part[1] = part2; f.out[1] = NH > 1 ? hb[3] : dtq; f.n_red = 2;
+        if ((rc = mpo_launch_bag_finish(f, n_slides, n_q, EH, splits, stream))) return rc;
+        if (NH > 1) {
+            if ((rc = copy_cols(dqt + h * EH, E, hb[2], EH, R, EH, stream))) return rc;
+            if ((rc = copy_cols(dtq + h * EH, E, hb[3], EH, R, EH, stream))) return rc;
+        }
     }
     if ((rc = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
     if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0),
                                   mpo_args_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f), stream))) return rc;
     // bag side: dK = ds1^T q~ + (dg^T tq) * (1 - TK^2),  dH = A_drop^T dctx
     // (one pass: tanh' from the staged K tile)
-    if ((rc = mpo_launch_bag_outer_gated(static_cast<const float*>(kbag), cu_rows, n_slides, E, ds1_map, qt, dg_map, tq,
-                                         d_kbag, dk_dtype == MPO_F32, part_cs, n_q, splits, stream))) return rc;
-    {   // one launch: the key bag's column sums, and zeros for the key slice of the packed in-projection (it belongs to
-        // the caller's K = H W_k^T + b_k; a caller may have the key-bias gradient written straight into its slice)
+    for (int h = 0; h < NH; ++h) {
+        const float *qth = qt, *tqh = tq;
+        if (NH > 1) {
+            if ((rc = copy_cols(hb[4], EH, qt + h * EH, E, R, EH, stream))) return rc;
+            if ((rc = copy_cols(hb[5], EH, tq + h * EH, E, R, EH, stream))) return rc;
+            qth = hb[4]; tqh = hb[5];
+        }
+        if ((rc = mpo_launch_bag_outer_gated(reinterpret_cast<const float*>(static_cast<const char*>(kbag) + h * half_k), cu_rows,
+                                             n_slides, EH, ds1_map, qth, dg_map, tqh, static_cast<char*>(d_kbag) + h * half_dk,
+                                             dk_dtype == MPO_F32, part_cs, n_q, splits, stream))) return rc;
+        // one launch: the key bag's column sums, and (first half) zeros for the key slice of the packed in-projection (it
+        // belongs to the caller's K = H W_k^T + b_k; a caller may have the key-bias gradient written straight into its slice)
         BagFinish f{};
-        f.part_cs = d_kbag_colsum ? part_cs : nullptr; f.colsum = d_kbag_colsum; f.cs_cols = E;
-        f.zero[0] = d_in_w + (size_t)E * E; f.n_zero[0] = E * E;
-        if (d_kbag_colsum != d_in_b + E) { f.zero[1] = d_in_b + E; f.n_zero[1] = E; }
-        if ((rc = mpo_launch_bag_finish(f, n_slides, n_q, E, splits, stream))) return rc;
+        f.part_cs = d_kbag_colsum ? part_cs : nullptr; f.colsum = d_kbag_colsum ? d_kbag_colsum + h * EH : nullptr; f.cs_cols = EH;
+        if (h == 0) {
+            f.zero[0] = d_in_w + (size_t)E * E; f.n_zero[0] = E * E;
+            if (d_kbag_colsum != d_in_b + E) { f.zero[1] = d_in_b + E; f.n_zero[1] = E; }
+        }
+        if ((rc = mpo_launch_bag_finish(f, n_slides, n_q, EH, splits, stream))) return rc;
     }
     if (d_ctx == nullptr)
-        if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, E, attn_map, dctx, nullptr, nullptr, d_hbag, f32, n_q, splits, stream))) return rc;
+        for (int h = 0; h < NH; ++h)
+            if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, EH, attn_map, NH > 1 ? hb[h] : dctx, nullptr, nullptr,
+                                           static_cast<char*>(d_hbag) + h * half_h, f32, n_q, splits, stream))) return rc;
     return 0;
 }
 

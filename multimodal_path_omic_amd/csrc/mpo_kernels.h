@@ -271,6 +271,7 @@ int mpo_launch_head_loss(const float* logits, const long long* label, const floa
 int mpo_launch_counters_bump(unsigned long long* epoch, int* step, hipStream_t s);
 int mpo_launch_head_bwd(const float* hazards, const float* survs, const float* y, const float* dhz, const float* dsv,
                         const float* dy, float* dlogits, int B, int C, hipStream_t s);
+int mpo_launch_ew_add(float* acc, const float* b, size_t n, hipStream_t s);      // acc += b
 int mpo_launch_ew_mul(const float* a, const float* b, float* out, int n, hipStream_t s);
 int mpo_launch_ew_mul2(const float* x, const float* p, const float* q, float* xp, float* xq, int n, hipStream_t s);
 int mpo_launch_ew_add(const float* a, const float* b, float* out, int n, hipStream_t s);

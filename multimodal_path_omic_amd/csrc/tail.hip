@@ -659,6 +659,9 @@ __global__ void ew_mul_kernel(const float* __restrict__ a, const float* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] * b[i];
 }
+__global__ void ew_add_kernel(float* __restrict__ acc, const float* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc[i] += b[i];
+}
 __global__ void ew_mul2_kernel(const float* __restrict__ x, const float* __restrict__ p, const float* __restrict__ q,
                                float* __restrict__ xp, float* __restrict__ xq, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -882,6 +885,13 @@ int mpo_launch_head_loss(const float* logits, const long long* label, const floa
 }
 int mpo_launch_counters_bump(unsigned long long* epoch, int* step, hipStream_t s) {
     counters_bump_kernel<<<1, 64, 0, s>>>(epoch, step);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_ew_add(float* acc, const float* b, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    const size_t blocks = (n + 255) / 256;
+    ew_add_kernel<<<(unsigned)(blocks < 65536 ? blocks : 65536), 256, 0, s>>>(acc, b, n);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -192,21 +192,20 @@ class NarrowContextualAttentionGateTransformer(_FusionModelBase):
 
     def __init__(self, omic_sizes: [], model_size: str = "medium", n_classes: int = 4, dropout: float = 0.25,
                  fusion: str = "concat", device: str = "cpu", bag_dtype: torch.dtype = torch.float32):
-        if model_size == "big":
-            # the reference accepts it (models/nacagat/nacagat.py:17-18); K2's bag kernels exist for d = 128 / 256 only:
-            # say so here instead of failing inside the first forward
-            raise NotImplementedError("NarrowContextualAttentionGateTransformer(model_size='big') (embed_dim 512) is not built: "
-                                      "the narrow-gated co-attention kernels cover 'small' and 'medium'")
         super().__init__(omic_sizes, model_size, n_classes, dropout, fusion, device, bag_dtype)
 
     def _make_co_attention(self, d):
         return PreGatingContextualAttention(embed_dim=d, num_heads=1)
 
-    _fused_bag_gate = True
+    @property
+    def _fused_bag_gate(self):
+        # (the kernel that finishes d_bag with the patch layer's ReLU / dropout derivative is built for embed_dim <= 256; 'big'
+        #  runs the column-half passes of csrc/capi.hip and leaves that derivative to the patch layer's own backward)
+        return self.model_sizes[1] != 512
 
     def _co_attend(self, g_bag, h_bags, inference):
         gate = 0.0
-        if h_bags.data.dtype == torch.bfloat16:
+        if h_bags.data.dtype == torch.bfloat16 and self._fused_bag_gate:
             gate = getattr(h_bags.data, "_mpo_keep_scale", 1.0 / (1.0 - self.H[2].p)) if self.training else 1.0
         return self.co_attention.forward_window(g_bag, h_bags, bag_relu_gate=gate)
 

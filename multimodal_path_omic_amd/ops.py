@@ -1174,12 +1174,25 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         ctx.bag_bias = getattr(bag_data, "_mpo_bias_param", None)
         if ctx.bag_relu_gate != 0.0 and bag_data.dtype != torch.bfloat16:
             raise ValueError("bag_relu_gate (fused ReLU/dropout derivative of the patch layer) needs a bf16-stored bag")
+        big = E == 512
+        if big and ctx.bag_relu_gate != 0.0:
+            raise ValueError("embed_dim 512: the fused ReLU/dropout gate of the patch layer is built for embed_dim <= 256")
+        hb = bag_data
         if bag_data.dtype == torch.bfloat16 and E == 256:
             # HIP key projection: bf16 bag (exact) x fp32 weights split into three bf16 terms, fp32 accumulate and output
             kbag = torch.empty(T, E, device=dev, dtype=torch.float32)
             w_k, b_k = in_w[E:2 * E], in_b[E:2 * E]
             L.check(lib.mpo_key_projection(L.ptr(bag_data), T, E, L.ptr(w_k), L.ptr(b_k), L.ptr(kbag), L.stream_of(query)),
                     "mpo_key_projection")
+        elif big:
+            # 'big' (models/nacagat/nacagat.py:17-18): both bags in the split-halves layout [2][T][256] of include/mpo_hip.h --
+            # K half h straight out of its own GEMM (rows 256 h .. of W_k), the bag as one strided copy
+            xf = bag_data.float().contiguous()
+            kbag = torch.empty(2, T, 256, device=dev, dtype=torch.float32)
+            for h in range(2):
+                L.check(lib.mpo_linear_forward(L.ptr(xf), L.ptr(in_w[E + 256 * h:E + 256 * (h + 1)]), L.ptr(in_b[E + 256 * h:E + 256 * (h + 1)]),
+                                               L.ptr(kbag[h]), T, E, 256, 1.0, L.ACT["none"], L.stream_of(query)), "mpo_linear_forward")
+            hb = bag_data.view(T, 2, 256).permute(1, 0, 2).contiguous()
         else:
             # fp32 bag (or the small model's bf16 bag): the exact-fp32 MFMA GEMM of the token tail in its many-row form
             kbag = torch.empty(T, E, device=dev, dtype=torch.float32)
@@ -1193,11 +1206,12 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         ws = _workspace(lib.mpo_nacagat_workspace_bytes(n_slides, n_q, E, batch.max_rows, T), dev)
         seed, offset = next_dropout_stream(n_q * T) if drop_p > 0 else (0, 0)
         L.check(lib.mpo_coattn_nacagat_forward(
-            L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, T, batch.max_rows,
+            L.ptr(kbag), L.MPO_F32, L.ptr(hb), L.bag_dtype_code(bag_data), L.ptr(batch.cu), n_slides, T, batch.max_rows,
             L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), L.ptr(out_b), float(drop_p), seed, offset,
             _epoch(), L.ptr(q_proj), L.ptr(out), L.ptr(amap), L.ptr(score_maps), L.ptr(saved),
             batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_forward")
         ctx.save_for_backward(query, bag_data, kbag, in_w, in_b, out_w, saved, score_maps, amap)
+        ctx.hb = hb if big else None                  # (the split-halves copy of the bag: kept for the backward)
         ctx.param_refs = (in_w, in_b, out_w, out_b)
         ctx.batch, ctx.n_q, ctx.drop = batch, n_q, (float(drop_p), seed, offset)
         return q_proj, out, amap
@@ -1217,13 +1231,15 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         d_k = torch.empty_like(kbag, dtype=bag_data.dtype)       # a bf16 bag takes its key gradient in bf16 (see below)
         # bf16 bag: the patch-side gradient is finished by ONE pass after the dK W_k GEMM (mpo_nacagat_patch_grad) instead
         # of outer-product kernel -> addmm_ read-modify-write -> element-wise derivative pass
-        fused_patch = bag_data.dtype == torch.bfloat16
-        d_h = None if fused_patch else torch.empty_like(bag_data)
+        big = E == 512
+        hb = ctx.hb if big else bag_data
+        fused_patch = bag_data.dtype == torch.bfloat16 and not big
+        d_h = None if fused_patch else torch.empty_like(hb)
         d_ctx = torch.empty(R, E, device=dev, dtype=torch.float32) if fused_patch else None
         d_in_w, d_in_b, d_out_w, d_out_b = (grad_out(p) for p in ctx.param_refs)
         ws = _workspace(lib.mpo_nacagat_workspace_bytes(batch.n_slides, n_q, E, batch.max_rows, T), dev)
         L.check(lib.mpo_coattn_nacagat_backward(
-            L.ptr(kbag), L.MPO_F32, L.ptr(bag_data), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
+            L.ptr(kbag), L.MPO_F32, L.ptr(hb), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
             _epoch(), L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
             L.ptr(d_query), L.ptr(d_k), L.bag_dtype_code(d_k), L.ptr(d_in_b[E:2 * E]), L.ptr(d_h), L.ptr(d_ctx), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
@@ -1251,6 +1267,16 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
             if colsum is not None:
                 d_h._mpo_colsum = colsum          # the producing layer's bias gradient (PatchFcFn.backward picks it up)
             patch_weight_grad(d_k, bag_data, d_in_w[E:2 * E])     # dW_k = d_k^T H_bag (hand-written for 256 x 256, bf16)
+        elif big:
+            # split-halves results back to [T, 512], then the two products through the key projection on the fp32 MFMA GEMMs
+            # (a bf16 bag: in fp32, rounded once on the way out)
+            s_ = L.stream_of(query)
+            dkf = d_k.permute(1, 0, 2).reshape(T, E).float().contiguous()
+            dhf = d_h.permute(1, 0, 2).reshape(T, E).float().contiguous()
+            L.check(lib.mpo_linear_backward_input(L.ptr(dkf), L.ptr(w_k), L.ptr(dhf), T, E, E, 1.0, 1, s_), "mpo_linear_backward_input")
+            L.check(lib.mpo_linear_backward_weight(L.ptr(dkf), L.ptr(bag_data.float().contiguous()), L.ptr(d_in_w[E:2 * E]), None, T, E, E,
+                                                   1.0, s_), "mpo_linear_backward_weight")
+            d_h = dhf.to(bag_data.dtype)
         else:
             # fp32 bag: d_h += d_k W_k and dW_k = d_k^T H on the fp32 MFMA GEMMs (many-row / long-K forms)
             s_ = L.stream_of(query)

@@ -12,9 +12,11 @@ from oracle import mpo_oracle as O
 from multimodal_path_omic_amd.ops import make_cu as ops_make_cu
 
 pytestmark = pytest.mark.gpu
-# gradient bars = about twice the measured worst case (printed per case, pytest -rA)
-GRAD_TOL_PEAKY = 1e-2
-GRAD_TOL_BF16_BAG = 1.5e-2
+# gradient bars = about twice the measured worst case (printed per case, pytest -rA; r03: peaky fixture 2.9e-3 fp32 bag /
+# 5.0e-3 bf16 bag; bf16 bag: d_bag 3.2e-3, parameters 2.5e-3)
+GRAD_TOL_PEAKY = 6e-3
+GRAD_TOL_PEAKY_BF16 = 1e-2
+GRAD_TOL_BF16_BAG = 7e-3
 GRAD_TOL_BF16_PARAM = 5e-3
 sub = syn.subsample
 
@@ -93,7 +95,7 @@ def test_nacagat_forward_backward(dev, golden, case, dtype):
         if not f32:
             # bf16 bag: d_bag is emitted in bf16 and the key-projection gradients (dW_k, dH += dK W_k) run
             # through bf16 operands with fp32 accumulation
-            tol = GRAD_TOL_BF16_BAG if n == "bag" else max(tol, GRAD_TOL_BF16_PARAM)
+            tol = GRAD_TOL_BF16_BAG if n == "bag" else (GRAD_TOL_PEAKY_BF16 if peaky else GRAD_TOL_BF16_PARAM)
         e = relerr(gr, g1_o[n])
         worst[n] = e
         assert e < tol, (n, e)

@@ -257,7 +257,7 @@ def test_small_model_size_matches_oracle(dev, kind, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_big_mcat_matches_oracle(dev, dtype):
     """MCAT model_size='big' (d = 512, models/mcat/mcat.py:20-21): the E = 512 instantiations of K1 forward and backward
-    (2 / 1 waves per workgroup to fit LDS; functional, not tuned) against the oracle.  NaCAGaT 'big' is not built."""
+    (2 / 1 waves per workgroup to fit LDS; functional, not tuned) against the oracle."""
     omic_sizes, m, seed = [64, 100, 256, 31, 8, 300], 1200, 6160
     model = MultimodalCoAttentionTransformer(omic_sizes=omic_sizes, model_size="big", bag_dtype=dtype)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -285,6 +285,45 @@ def test_big_mcat_matches_oracle(dev, dtype):
         # dW_H by |dH| |x| ~ 3e-5, i.e. 6e-3 of this fixture's tiny gradient scale (tools/gpu_diag_big4.py: the gradient
         # ARRIVING at H_bag agrees to 4e-6)
         tol = (1e-2 if n.startswith("H.") else 2e-3) if dtype == torch.float32 else (2e-2 if n.startswith("H.") else 1e-2)
+        assert err < tol, (n, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_big_nacagat_matches_oracle(dev, dtype):
+    """NaCAGaT model_size='big' (d = 512, models/nacagat/nacagat.py:17-18): K2's bag passes run once per column half of the
+    split-halves bag layout on the 256-wide kernels (csrc/capi.hip; functional, not tuned) -- forward, map and every parameter
+    gradient against the oracle, on a ragged two-slide window so that the halves' strided copies see several query rows."""
+    omic_sizes, seed = [64, 100, 256, 31, 8, 300], 6262
+    lengths = [1200, 77]
+    model = NarrowContextualAttentionGateTransformer(omic_sizes=omic_sizes, model_size="big", bag_dtype=dtype)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert shapes["H.0.weight"] == (512, 1024) and shapes["co_attention.in_proj_weight"] == (1536, 512)
+    sd = syn.fill_state_dict(shapes, seed)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    g = syn.rng(seed + 1)
+    wsis = [syn.normal(g, (m, 1024)) for m in lengths]
+    omics = [[syn.normal(g, (s,)) for s in omic_sizes] for _ in lengths]
+    labels, cens = torch.tensor([3, 1]), torch.tensor([0.0, 1.0])
+    bags = BagBatch.from_list([w.to(dev).to(dtype) for w in wsis])
+    om_w = [torch.stack([omics[b][i] for b in range(len(lengths))]).to(dev) for i in range(len(omic_sizes))]
+    hz_w, sv_w, _, att_w = model.forward_window(bags, om_w, inference=True)
+    ces_loss(hz_w, sv_w, labels.to(dev), cens.to(dev), reduction="sum").backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kw = dict(bag_storage=torch.bfloat16, round_gemm_out=True) if dtype == torch.bfloat16 else {}   # (d = 512: the library-GEMM patch layer)
+    for b, m in enumerate(lengths):
+        hz_o, sv_o, _, att_o = O.nacagat_forward(p, wsis[b], omics[b], **kw)
+        assert float((hz_w[b].cpu() - hz_o[0]).abs().max()) < 2e-4
+        a, a_o = att_w["coattn"][b].cpu(), att_o["coattn"].detach()
+        rel = ((a - a_o).abs() / a_o.clamp_min(1e-30)).max().item()
+        print(f"[big nacagat] {dtype} slide {b} ({m} rows): co-attention map rel err {rel:.2e}")
+        assert rel < (1e-3 if dtype == torch.float32 else 3e-3), rel       # bf16: K comes from the bf16 bag's own rounding of H W_k^T inputs
+        O.ces_loss(hz_o, sv_o, labels[b:b + 1], cens[b:b + 1]).backward()
+    for n, prm in model.named_parameters():
+        ref = p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])
+        scale = max(float(ref.abs().max()), 1e-4)
+        err = float((prm.grad.cpu() - ref).abs().max()) / scale
+        tol = (1e-2 if n.startswith("H.") else 3e-3) if dtype == torch.float32 else (2e-2 if n.startswith("H.") else 1e-2)
         assert err < tol, (n, err)
 
 

@@ -101,13 +101,18 @@ def test_c_index_vectorised_equals_oracle_loop():
         assert harness.concordance_index_censored(event, time, risk) == pytest.approx(ref, abs=1e-12)
 
 
-def test_unbuilt_model_size_is_refused_at_construction():
-    from multimodal_path_omic_amd.models import (MultimodalCoAttentionTransformer,
+def test_model_sizes_of_the_reference_construct():
+    """small / medium / big (models/mcat/mcat.py:16-21, models/nacagat/nacagat.py:13-18) for both fusion models; the one size
+    still refused is the gene-expression model's 'big' (one attention head of 512 over the bag's rows), at construction."""
+    from multimodal_path_omic_amd.models import (GeneExprNarrowContextualAttentionGateTransformer,
+                                                 MultimodalCoAttentionTransformer,
                                                  NarrowContextualAttentionGateTransformer)
+    for size, d in (("small", 128), ("medium", 256), ("big", 512)):
+        for cls in (MultimodalCoAttentionTransformer, NarrowContextualAttentionGateTransformer):
+            m = cls(omic_sizes=[8] * 6, model_size=size)
+            assert tuple(m.co_attention.in_proj_weight.shape) == (3 * d, d)
     with pytest.raises(NotImplementedError, match="big"):
-        NarrowContextualAttentionGateTransformer(omic_sizes=[8] * 6, model_size="big")
-    MultimodalCoAttentionTransformer(omic_sizes=[8] * 6, model_size="big")          # MCAT 'big' is built
-    NarrowContextualAttentionGateTransformer(omic_sizes=[8] * 6, model_size="small")
+        GeneExprNarrowContextualAttentionGateTransformer(model_size="big")
 
 
 def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
