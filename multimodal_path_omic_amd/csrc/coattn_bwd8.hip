@@ -9,8 +9,8 @@
 // resident on the SIMD to issue meanwhile (r02: 0.44-0.47 of HBM peak inside the step; the same pass with tiles direct to LDS
 // and 186 + 256 registers did not move, NOTES.md).  Here a wave fits 256 registers, so two waves share a SIMD and one
 // computes while the other waits for its tile:
-//   * query-side operands (qk hi/lo, dctx hi/lo) are 16-byte MFMA fragments in LDS, compact [array][k-step][lane group][query
-//     slot] with one zero slot for the dead MFMA rows / columns (18 KiB per workgroup instead of 128 registers per lane);
+//   * query-side operands (qk hi/lo, dctx hi/lo) are 16-byte MFMA fragments in LDS, compact [array][k-step][lane group][8 query
+//     slots] (16 KiB per workgroup instead of 128 registers per lane);
 //   * ONE tile image per wave, filled global -> LDS directly (global_load_lds_dwordx4, the image's chunk swizzle applied to the
 //     GLOBAL chunk a lane fetches); no staging registers.  A wave requests its next tile right after the copy-out of the
 //     current one has read the image and then waits for it -- the sibling wave of the SIMD is in its compute phase meanwhile;
@@ -22,11 +22,12 @@
 //   * dH leaves the MFMA as 4 consecutive embed columns of one patch row per lane (8 bytes).  The general kernel stores those
 //     8-byte slots (4-way bank conflicts: 47 % of its LDS cycles, r01 SQ counters).  Here lane groups g and g ^ 1 exchange
 //     halves (v_permlane16_swap_b32: a lane then owns ONE 16-byte chunk of one row), so the ReLU/dropout gate reads H and the
-//     store writes dH as conflict-free ds_read_b128 / ds_write_b128 in the row-operand pattern of the image;
+//     store writes dH as ds_read_b128 / ds_write_b128 (reads conflict-free with the image swizzle below; the stores stay
+//     2-way -- eight consecutive rows per store group -- at a cost below the instruction's own 13 cycles);
 //   * the Z^T operand of the dH product is kept for lane groups 0 / 1 only (queries 0..7; 8 KiB): the A / dS values of dead
 //     queries are exact zeros, so what their k-slots multiply is irrelevant as long as it is finite.  The gate's scale
 //     1 / (1 - p) is folded into Z.
-// LDS: 8 x 16 KiB images + 8 KiB Z + 18 KiB query fragments = 154 KiB.
+// LDS: 8 x 16 KiB images + 8 KiB Z + 16 KiB query fragments = 152 KiB.
 //
 // Roofline: HBM.  Algorithmic bytes per patch row 2 x 512 (H_bag read, dH written); 32 x 15 000 rows: 491.52 MB per launch.
 #include "coattn_tile.h"
@@ -36,14 +37,38 @@ namespace {
 
 constexpr int E8 = 256;
 constexpr int W8 = 8;                                     // waves per workgroup: two per SIMD
-constexpr int QS = 9;                                     // query slots of a fragment row: 8 live + the zero slot
+constexpr int QS = 8;                                     // query slots of a fragment row (dead slots hold zeros)
 using G8 = TileGeom<E8>;
 constexpr int OFF_Z8 = W8 * G8::TILEB;                    // 131 072
 constexpr int Z8_BYTES = G8::DT * 32 * 16;                // [t][lane group 0 / 1][16 lanes] fragments: 8 KiB
 constexpr int OFF_QF8 = OFF_Z8 + Z8_BYTES;                // 139 264
-constexpr int QF8_ARR = G8::KS * 4 * QS * 16;             // one operand array [k-step][lane group][slot]: 4 608 B
-constexpr int LDS8 = OFF_QF8 + 4 * QF8_ARR;               // 157 696
+constexpr int QF8_ARR = G8::KS * 4 * QS * 16;             // one operand array [k-step][lane group][slot]: 4 KiB
+constexpr int LDS8 = OFF_QF8 + 4 * QF8_ARR;               // 155 648
 static_assert(LDS8 <= 160 * 1024, "LDS budget");
+
+// Image layout: row-major 512-byte rows, 16-byte chunk c of row r at  c ^ sw8(r),  sw8(r) = 2 (r & 7) ^ (r >> 4): K1's
+// swizzle (coattn_tile.h) with the 16-row half of the tile folded into bit 0.  Row-operand reads (one 16-row half per
+// instruction) and transposed reads are conflict-free as with K1's; the extra bit makes the per-lane 16-byte dH slots
+// conflict-free too: a ds_read_b128 lane group mixes lane groups g and g + 1 (MI355X_MICROARCH.md, LDS), which own the SAME
+// chunk of rows 16 apart -- without the bit they would sit on the same banks (measured: 38 % of the kernel's LDS cycles).
+__device__ __forceinline__ int sw8(int r) { return ((r & 7) << 1) ^ ((r >> 4) & 1); }
+__device__ __forceinline__ bf16x8 row_frag8(const char* tile, int pt, int s, int lane) {
+    const int p = lane & 15, g = lane >> 4;
+    const int c = (4 * s + g) ^ ((lane & 7) << 1) ^ pt;
+    return *reinterpret_cast<const bf16x8*>(tile + (16 * pt + p) * G8::ROWB + (c << 4));
+}
+__device__ __forceinline__ bf16x8 col_frag8(const char* tile, int t, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int q4 = i >> 2, p4 = i & 3;
+    const int r0 = 4 * g + q4;                       // rows r0 (half 0) and 16 + r0 (half 1: bit 0 of the chunk flipped)
+    const int c = (2 * t + (p4 >> 1)) ^ ((r0 & 7) << 1);
+    const int off = r0 * G8::ROWB + 8 * (p4 & 1);
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + off + (c << 4)));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + off + ((c ^ 1) << 4) + 16 * G8::ROWB));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
 
 __device__ __forceinline__ unsigned lds_addr8(const char* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
@@ -86,7 +111,7 @@ void coattn_bwd8_kernel(const __bf16* __restrict__ bag, const int* __restrict__ 
     char* dslide = reinterpret_cast<char*>(dbag) + (size_t)row_begin * G8::ROWB;
 
     // rows [trow, trow + 32) of the slide -> this wave's image: instruction i carries rows 2 i, 2 i + 1 (1 KiB, linear on the
-    // LDS side); lane (row = lane >> 5, position = lane & 31) fetches the global chunk position ^ 2 (row & 7), which is the
+    // LDS side); lane (row = lane >> 5, position = lane & 31) fetches the global chunk position ^ sw8(row), which is the
     // chunk the image keeps at that position.  Rows past the slide are clamped (finite data; masked below).
     auto issue_tile = [&](int trow) {
         int el = lane;
@@ -95,7 +120,7 @@ void coattn_bwd8_kernel(const __bf16* __restrict__ bag, const int* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = 2 * i + rl;
-            const int c = cpos ^ ((r & 7) << 1);
+            const int c = cpos ^ sw8(r);
             const int grow = min(trow + r, m_rows - 1);
             glds16_8(slide + (size_t)grow * G8::ROWB + (c << 4), img_lds + i * 1024);
         }
@@ -199,11 +224,13 @@ void coattn_bwd8_kernel(const __bf16* __restrict__ bag, const int* __restrict__ 
             f32x4 sT[2], dT[2], sN[2], dN[2];
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) sT[pt] = dT[pt] = sN[pt] = dN[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const char* qf = lds + OFF_QF8 + ((eg * QS + (ec < n_q ? ec : QS - 1)) << 4);
+            // (dead MFMA rows / columns -- queries n_q..15 -- read slot ec & 7: zeros, or a live query's finite fragment whose
+            //  products the +inf log-sum-exp below turns into exact zeros; lanes ec and ec + 8 share an address: a broadcast)
+            const char* qf = lds + OFF_QF8 + ((eg * QS + (ec & 7)) << 4);
 #pragma unroll
             for (int s = 0; s < G8::KS; ++s) {
-                const bf16x8 a0 = row_frag<E8>(img, 0, s, el);
-                const bf16x8 a1 = row_frag<E8>(img, 1, s, el);
+                const bf16x8 a0 = row_frag8(img, 0, s, el);
+                const bf16x8 a1 = row_frag8(img, 1, s, el);
                 const char* qs = qf + s * (4 * QS * 16);
                 const bf16x8 qh = *reinterpret_cast<const bf16x8*>(qs);
                 const bf16x8 ql = *reinterpret_cast<const bf16x8*>(qs + QF8_ARR);
@@ -255,14 +282,19 @@ void coattn_bwd8_kernel(const __bf16* __restrict__ bag, const int* __restrict__ 
             pack_hi_lo(ds, wh, wl);
         }
         // ---------------- dqk^T[d][q] += H^T[d][p] dS^T[p][q]   (reads the H image: before dH overwrites it)
-        tile_accum_cols<E8, 1>(img, img, wh, wl, accq, el);
+#pragma unroll
+        for (int t = 0; t < G8::DT; ++t) {
+            const bf16x8 hf = col_frag8(img, t, el);
+            accq[t] = mfma_bf16(hf, wh, accq[t]);
+            accq[t] = mfma_bf16(hf, wl, accq[t]);
+        }
 
         // ---------------- dH^T[d][p] = Z^T W^T; lane groups g, g ^ 1 exchange halves, the lane then owns the 16-byte chunk
         // 2 t + (g >> 1) of row 16 (g & 1) + (lane & 15): gate against H read from that very slot, dH written over it
         {
             const int row = 16 * (eg & 1) + ec;
             char* rowp = img + row * G8::ROWB;
-            const int swz = (row & 7) << 1, chi = eg >> 1;
+            const int swz = sw8(row), chi = eg >> 1;
             const char* zf = lds + OFF_Z8 + ((((eg & 1) << 4) + ec) << 4);
 #pragma unroll
             for (int t = 0; t < G8::DT; ++t) {
@@ -301,7 +333,7 @@ void coattn_bwd8_kernel(const __bf16* __restrict__ bag, const int* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r = 2 * i + rl;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(img + r * G8::ROWB + ((cc ^ ((r & 7) << 1)) << 4));
+                const f32x4 v = *reinterpret_cast<const f32x4*>(img + r * G8::ROWB + ((cc ^ sw8(r)) << 4));
                 if (r < nvalid) *reinterpret_cast<f32x4*>(dslide + ((size_t)(trow + r) * 32 + cc) * 16) = v;
                 if (part_colsum != nullptr) {                     // (rows past the range carry exact zeros: A = 0 there)
                     const bf16x8 hv = __builtin_bit_cast(bf16x8, v);

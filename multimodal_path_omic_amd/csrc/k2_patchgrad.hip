@@ -30,6 +30,9 @@ using PGG = TileGeom<PG_E>;                                  // ROWB 512, TILEB 
 constexpr int PG_MAPB = kTileRows * 16 * 4;                  // map values of a tile: [32 rows][16 queries] floats = 2 KiB
 constexpr int PG_BUF = 2 * PGG::TILEB + PG_MAPB;             // dK image | H image (becomes the output image) | map values
 typedef unsigned int pg_u32x4 __attribute__((ext_vector_type(4)));
+// chunk swizzle of the H / output image: K1's 2 (r & 7) with the 16-row half folded into bit 0 -- a ds_read_b128 lane group
+// mixes lane groups g and g + 1, which own the same chunk of rows 16 apart (see coattn_bwd8.hip)
+__device__ __forceinline__ int pg_sw(int r) { return ((r & 7) << 1) ^ ((r >> 4) & 1); }
 
 __global__ __launch_bounds__(PG_THREADS, 1)
 void k2_patch_grad_kernel(const int* __restrict__ cu, const pg_u32x4* __restrict__ dk, const float* __restrict__ w_k,
@@ -96,9 +99,8 @@ void k2_patch_grad_kernel(const int* __restrict__ cu, const pg_u32x4* __restrict
         for (int i = 0; i < 2; ++i) {
             const int ci = tid + i * PG_THREADS;
             const int r = ci >> 5, cc = ci & 31;
-            const int off = r * PGG::ROWB + ((cc ^ ((r & 7) << 1)) << 4);
-            *reinterpret_cast<pg_u32x4*>(buf + off) = kk[i];
-            *reinterpret_cast<pg_u32x4*>(buf + PGG::TILEB + off) = hh[i];
+            *reinterpret_cast<pg_u32x4*>(buf + r * PGG::ROWB + ((cc ^ ((r & 7) << 1)) << 4)) = kk[i];
+            *reinterpret_cast<pg_u32x4*>(buf + PGG::TILEB + r * PGG::ROWB + ((cc ^ pg_sw(r)) << 4)) = hh[i];
         }
         const bool live = mq < n_q && r0 + kTileRows * it + mr < r1;           // dead queries / rows past the range: zero
         reinterpret_cast<float*>(buf + 2 * PGG::TILEB)[mr * 16 + mq] = live ? mm : 0.f;
@@ -144,7 +146,7 @@ void k2_patch_grad_kernel(const int* __restrict__ cu, const pg_u32x4* __restrict
         // lane groups g, g ^ 1 exchange halves: the lane then owns chunk 4 wave + 2 ct + (g >> 1) of row 16 (g & 1) + c16
         const int row = 16 * (g & 1) + c16;
         char* rowp = imh + row * PGG::ROWB;
-        const int swz = (row & 7) << 1;
+        const int swz = pg_sw(row);
         const float sc = gate != 0.f ? gate : 1.0f;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -173,7 +175,7 @@ void k2_patch_grad_kernel(const int* __restrict__ cu, const pg_u32x4* __restrict
         for (int i = 0; i < 2; ++i) {                              // whole rows out + their column sums
             const int ci = tid + i * PG_THREADS;
             const int r = ci >> 5, cc = ci & 31;
-            const pg_u32x4 v = *reinterpret_cast<const pg_u32x4*>(imh + r * PGG::ROWB + ((cc ^ ((r & 7) << 1)) << 4));
+            const pg_u32x4 v = *reinterpret_cast<const pg_u32x4*>(imh + r * PGG::ROWB + ((cc ^ pg_sw(r)) << 4));
             if (r < nvalid) {
                 os[(size_t)(row0 + r) * 32 + cc] = v;
                 if (part_colsum != nullptr) {

@@ -6,7 +6,7 @@ Two INDEPENDENT captured steps (model replica + gradient bucket + optimiser each
 against the product's single 32-slide step.  Repeated with the bag kernels' work plans cut to fewer workgroups than CUs
 (ops.plan_workgroups), which leaves whole CUs to the other stream's launches (a persistent bag workgroup takes a CU's LDS
 and register file, so nothing co-resides with it).
-    python tools/gpu_probe_overlap.py [slides_per_half] [patches]"""
+    python tools/gpu_probe_overlap.py [slides_per_half] [patches] [targets, e.g. none,224]"""
 import sys
 import time
 
@@ -20,6 +20,7 @@ from multimodal_path_omic_amd.harness import GraphedWindowStep  # noqa: E402
 
 half = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 patches = int(sys.argv[2]) if len(sys.argv) > 2 else 15000
+targets = [None if t == "none" else int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [None, 240, 224, 192, 128]
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 
@@ -63,7 +64,7 @@ def serial(a, b):
     return fn
 
 
-for target in (None, 240, 224, 192, 128):
+for target in targets:
     ops.plan_workgroups = target
     full = make_step(2 * half, 1)
     t_full = timed(lambda: full.graph.replay())
