@@ -126,53 +126,83 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) acc[ct][rt] = zero4;
-        f32x4 xs[4];
-        f16x8 wh[4], wl[4], whn[4], wln[4];
+        // Operand pipeline, three register sets each in static rotation (three steps per trip, no copies): step k multiplies the
+        // images of x(k) (LDS stage k & 1) by weight set k % 3, requests x(k + 2) and the weight fragments of step k + 2, and
+        // splits x(k + 1) -- requested in the previous step -- into the other stage AFTER the step's MFMAs are issued (four sets
+        // each, three steps ahead, spilled 98 registers).  One step of matrix work (~0.8 us) does not
+        // cover an HBM or a loaded-L2 round trip: with one step of lookahead every step began by waiting for its operands.
+        f32x4 xs[3][4];
+        f16x8 wh[3][4], wl[3][4];
+        auto load_x = [&](f32x4 (&dst)[4], int k) {
+            k = k < FSTEPS ? k : FSTEPS - 1;                              // (past the end: re-reads the last tile, never used)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xs[j] = *reinterpret_cast<const f32x4*>(xrow + 4 * j);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            wh[ct] = whi[ct * 64];
-            wl[ct] = wlo[ct * 64];
-        }
-#pragma unroll 2
-        for (int k = 0; k < FSTEPS; ++k) {
-            char* st = lds + (k & 1) * (2 * FIMG);
-            {   // split the staged X tile of this step into its hi / lo images
-                f16x8 h0, l0, h1, l1;
-                split8h(xs[0], xs[1], 1.0f, h0, l0);
-                split8h(xs[2], xs[3], 1.0f, h1, l1);
-                *reinterpret_cast<f16x8*>(st + soff0) = h0;
-                *reinterpret_cast<f16x8*>(st + soff1) = h1;
-                *reinterpret_cast<f16x8*>(st + FIMG + soff0) = l0;
-                *reinterpret_cast<f16x8*>(st + FIMG + soff1) = l1;
-            }
-            const int kn = k + 1 < FSTEPS ? k + 1 : k;                    // (the last step re-reads its own operands)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xs[j] = *reinterpret_cast<const f32x4*>(xrow + FBK * kn + 4 * j);
+            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const f32x4*>(xrow + FBK * k + 4 * j);
+        };
+        auto load_w = [&](f16x8 (&h_)[4], f16x8 (&l_)[4], int k) {
+            k = k < FSTEPS ? k : FSTEPS - 1;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                whn[ct] = whi[(kn * 4 + ct) * 64];
-                wln[ct] = wlo[(kn * 4 + ct) * 64];
+                h_[ct] = whi[(k * 4 + ct) * 64];
+                l_[ct] = wlo[(k * 4 + ct) * 64];
             }
-            __syncthreads();
+        };
+        auto split_tile = [&](const f32x4 (&src)[4], char* st) {
+            f16x8 h0, l0, h1, l1;
+            split8h(src[0], src[1], 1.0f, h0, l0);
+            split8h(src[2], src[3], 1.0f, h1, l1);
+            *reinterpret_cast<f16x8*>(st + soff0) = h0;
+            *reinterpret_cast<f16x8*>(st + soff1) = h1;
+            *reinterpret_cast<f16x8*>(st + FIMG + soff0) = l0;
+            *reinterpret_cast<f16x8*>(st + FIMG + soff1) = l1;
+        };
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            load_x(xs[j], j);
+            load_w(wh[j], wl[j], j);
+        }
+        split_tile(xs[0], lds);
+        // one K-step with the register sets named statically: j = k % 3
+        auto step = [&](int k, const f16x8 (&wh_)[4], const f16x8 (&wl_)[4], f16x8 (&whn)[4], f16x8 (&wln)[4], f32x4 (&xn)[4],
+                        const f32x4 (&xsplit)[4]) {
+            const char* st = lds + (k & 1) * (2 * FIMG);
+            __syncthreads();                                              // the images of x(k) are complete; the other stage is free
+            load_x(xn, k + 2);
+            load_w(whn, wln, k + 2);
+            f16x8 xh[8], xl[8];
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) {
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(st + rt * 16 * FROWB + foff);
-                const f16x8 xl = *reinterpret_cast<const f16x8*>(st + FIMG + rt * 16 * FROWB + foff);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    acc[ct][rt] = mfma_f16(wh[ct], xh, acc[ct][rt]);
-                    acc[ct][rt] = mfma_f16(wh[ct], xl, acc[ct][rt]);
-                    acc[ct][rt] = mfma_f16(wl[ct], xh, acc[ct][rt]);
-                }
+                xh[rt] = *reinterpret_cast<const f16x8*>(st + rt * 16 * FROWB + foff);
+                xl[rt] = *reinterpret_cast<const f16x8*>(st + FIMG + rt * 16 * FROWB + foff);
             }
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                wh[ct] = whn[ct];
-                wl[ct] = wln[ct];
+            for (int rt = 0; rt < 8; ++rt) {
+                // term-major: the three MFMAs of one accumulator are DEPENDENT (each waits for the previous result); with the
+                // four column tiles in between every MFMA finds its accumulator ready
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct][rt] = mfma_f16(wh_[ct], xh[rt], acc[ct][rt]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct][rt] = mfma_f16(wh_[ct], xl[rt], acc[ct][rt]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct][rt] = mfma_f16(wl_[ct], xh[rt], acc[ct][rt]);
             }
+            // (the scheduler otherwise sinks every read to its first use: reads first, four fragments ahead of the MFMAs)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);       // one row tile's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // the fragments of row tile j + 2
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            if (k + 1 < FSTEPS) split_tile(xsplit, lds + ((k + 1) & 1) * (2 * FIMG));       // (vector work behind the queued matrix work)
+        };
+#pragma unroll 1
+        for (int k = 0; k < FSTEPS - 2; k += 3) {                        // 30 steps, then the last two
+            step(k, wh[0], wl[0], wh[2], wl[2], xs[2], xs[1]);
+            step(k + 1, wh[1], wl[1], wh[0], wl[0], xs[0], xs[2]);
+            step(k + 2, wh[2], wl[2], wh[1], wl[1], xs[1], xs[0]);
         }
+        step(FSTEPS - 2, wh[0], wl[0], wh[2], wl[2], xs[2], xs[1]);
+        step(FSTEPS - 1, wh[1], wl[1], wh[0], wl[0], xs[0], xs[2]);
         // epilogue: acc[ct][rt][r] = H^T: embed column 64 wave + 16 ct + 4 g + r of patch row 16 rt + c16
         f32x4 bv[4];
 #pragma unroll
@@ -297,11 +327,11 @@ void patch_wgrad_f32_kernel(const float* __restrict__ dh,         // [rows][256]
             const bf16x8 bh = col_frag<256>(st + 2 * GIMG, 8 * xw + j, lane);
             const bf16x8 bl = col_frag<256>(st + 3 * GIMG, 8 * xw + j, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][j] = mfma_bf16(ah[i], bh, acc[i][j]);
-                acc[i][j] = mfma_bf16(ah[i], bl, acc[i][j]);
-                acc[i][j] = mfma_bf16(al[i], bh, acc[i][j]);
-            }
+            for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(ah[i], bh, acc[i][j]);      // (term-major: dependent MFMAs four apart)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(ah[i], bl, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(al[i], bh, acc[i][j]);
         }
     }
     // partial block: acc[i][j][r] = dW[64 gw + 16 i + 4 g + r][256 cb + 128 xw + 16 j + (lane & 15)]
