@@ -7,12 +7,13 @@ against the product's single 32-slide step.  Repeated with the bag kernels' work
 (ops.plan_workgroups), which leaves whole CUs to the other stream's launches (a persistent bag workgroup takes a CU's LDS
 and register file, so nothing co-resides with it).
     python tools/gpu_probe_overlap.py [slides_per_half] [patches] [targets, e.g. none,224]"""
+import os
 import sys
 import time
 
 import torch
 
-sys.path[:0] = ["."]
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import bench as B  # noqa: E402
 from multimodal_path_omic_amd import ops  # noqa: E402
 from multimodal_path_omic_amd.dp import FlatAdam, FlatGradBucket  # noqa: E402
