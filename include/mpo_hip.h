@@ -306,7 +306,7 @@ int mpo_encoder_backward(const float* x, int n_branches, int n_slides, int T, in
  * is the per-head context BEFORE out_proj.  saved: mpo_bag_self_attention_saved_floats() floats (one log-sum-exp per head
  * and row -- no M x M state is kept).  attn_map (nullable, heads == 1 only) [n_bags][M][M] = softmax(q k^T / sqrt(d)).
  * drop_p: dropout on the probabilities (realised round(256 p) / 256; regenerated in the backward from seed / offset /
- * *rng_epoch); the map is the undropped softmax.  Head dimension d / heads in {16, 32, 64, 128, 256}.
+ * *rng_epoch); the map is the undropped softmax.  Head dimension d / heads in {16, 32, 64, 128, 256, 512}.
  * Several heads of width 32 (the encoder layers) run on bf16 MFMAs with every operand split into hi + lo (three products
  * per term: ~16 mantissa bits); the forward then also stores the operands' bf16 forms in `saved` for the backward.
  * mpo_set_bag_self_attention_bf16x3(0) keeps that geometry on the fp32 kernels as well (verification hook; returns the

@@ -133,6 +133,18 @@ __device__ __forceinline__ void sa_tile_tacc(f32x4 (&acc)[HD / 16], const float*
     }
 }
 
+// the same for NCT 16-column groups starting at group ct0 (one column pass of a head wider than the register file)
+template <int HD, int NCT>
+__device__ __forceinline__ void sa_tile_tacc_cols(f32x4 (&acc)[NCT], const float* tile, int t, const f32x4& w, int j, int kk, int ct0) {
+    using C = SaCfg<HD>;
+    const float* base = tile + (16 * t + 4 * kk) * C::LDR + j + 16 * ct0;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(base[r * C::LDR + 16 * ct], w[r], acc[ct], 0, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // grid (query blocks of 64, heads, sequences).  o [M][d] (head h: columns h HD ..), lse2 [heads][M] = log2 of the row's
 // exp-sum in the scaled-by-log2(e) score domain.
@@ -317,7 +329,9 @@ void bag_sa_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ backward, dK and dV
-template <int HD>
+// NP column passes (grid.y = heads x NP): at HD = 512 the two key-side operands and both accumulators would take the whole
+// register file, so a pass recomputes the scores from full rows and accumulates HD / NP columns of dK and dV.
+template <int HD, int NP>
 __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ lse2, const float* __restrict__ delta,
                            const float* __restrict__ d_o, float* __restrict__ dqkv, int M, int d, float scale,
@@ -328,7 +342,8 @@ void bag_sa_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restric
     float* dot = sm + C::TILE_FLOATS;
     float* ls_t = sm + 2 * C::TILE_FLOATS;                   // [BN] lse2, then [BN] delta
     float* dl_t = ls_t + C::BN;
-    const int h = blockIdx.y, seq = blockIdx.z, H = gridDim.y;
+    constexpr int NCT = C::C16 / NP;                         // 16-column groups of this pass
+    const int h = blockIdx.y / NP, ct0 = (blockIdx.y % NP) * NCT, seq = blockIdx.z, H = gridDim.y / NP;
     qkv += (size_t)seq * M * 3 * d;
     dqkv += (size_t)seq * M * 3 * d;
     d_o += (size_t)seq * M * d;
@@ -340,9 +355,9 @@ void bag_sa_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restric
     float4 kf[C::C16], vf[C::C16];
     sa_load_frag<HD>(kf, qkv, 3 * d, d + h * HD, key, M, kk, scale * kLog2e);
     sa_load_frag<HD>(vf, qkv, 3 * d, 2 * d + h * HD, key, M, kk, 1.0f);
-    f32x4 dk[C::C16], dv[C::C16];
+    f32x4 dk[NCT], dv[NCT];
 #pragma unroll
-    for (int c = 0; c < C::C16; ++c) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int c = 0; c < NCT; ++c) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int q0 = 0; q0 < M; q0 += C::BN) {
         __syncthreads();
         sa_load_tile<HD>(qt, qkv, 3 * d, h * HD, q0, M);
@@ -371,14 +386,14 @@ void bag_sa_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restric
                 }
             }
             f32x4 ds = {p[0] * (dp[0] - dl.x), p[1] * (dp[1] - dl.y), p[2] * (dp[2] - dl.z), p[3] * (dp[3] - dl.w)};
-            sa_tile_tacc<HD>(dv, dot, t, pd, j, kk);
-            sa_tile_tacc<HD>(dk, qt, t, ds, j, kk);
+            sa_tile_tacc_cols<HD, NCT>(dv, dot, t, pd, j, kk, ct0);
+            sa_tile_tacc_cols<HD, NCT>(dk, qt, t, ds, j, kk, ct0);
         }
     }
     if (key < M) {
 #pragma unroll
-        for (int c = 0; c < C::C16; ++c) {
-            float* at = dqkv + (size_t)key * 3 * d + h * HD + 16 * c + 4 * kk;
+        for (int c = 0; c < NCT; ++c) {
+            float* at = dqkv + (size_t)key * 3 * d + h * HD + 16 * (ct0 + c) + 4 * kk;
             *reinterpret_cast<float4*>(at + d) = make_float4(dk[c][0] * scale, dk[c][1] * scale, dk[c][2] * scale, dk[c][3] * scale);
             *reinterpret_cast<float4*>(at + 2 * d) = make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]);
         }
@@ -410,7 +425,8 @@ int sa_backward(const float* qkv, const float* o, const float* lse2, const float
     const dim3 grid((M + 63) / 64, H, n_seq);
     bag_sa_bwd_dq_kernel<HD><<<grid, 64 * kSaWaves, 0, s>>>(qkv, o, lse2, d_o, dqkv, delta, M, d, scale, drop_p, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
-    bag_sa_bwd_dkv_kernel<HD><<<grid, 64 * kSaWaves, 0, s>>>(qkv, lse2, delta, d_o, dqkv, M, d, scale, drop_p, seed,
+    constexpr int NP = HD > 256 ? 2 : 1;
+    bag_sa_bwd_dkv_kernel<HD, NP><<<dim3(grid.x, H * NP, n_seq), 64 * kSaWaves, 0, s>>>(qkv, lse2, delta, d_o, dqkv, M, d, scale, drop_p, seed,
                                                                                          offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
@@ -1093,7 +1109,7 @@ inline bool sa_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15
 
 }  // namespace
 
-int mpo_bag_sa_supported_head_dim(int hd) { return hd == 16 || hd == 32 || hd == 64 || hd == 128 || hd == 256; }
+int mpo_bag_sa_supported_head_dim(int hd) { return hd == 16 || hd == 32 || hd == 64 || hd == 128 || hd == 256 || hd == 512; }
 int mpo_bag_sa_set_bf16x3(int enabled) {
     const int was = g_sa_b3 ? 1 : 0;
     g_sa_b3 = enabled != 0;
@@ -1118,7 +1134,7 @@ int mpo_launch_bag_sa_fwd(const float* qkv, int n_seq, int M, int d, int H, floa
     MPO_CHECK(n_seq >= 1 && M >= 1 && H >= 1 && d % H == 0, "bag self-attention: %d sequences of %d rows, d=%d, heads=%d", n_seq, M, d, H);
     MPO_CHECK(n_seq <= 65535 && H <= 65535, "bag self-attention: %d sequences x %d heads exceed the grid", n_seq, H);
     const int hd = d / H;
-    MPO_CHECK(mpo_bag_sa_supported_head_dim(hd), "bag self-attention: head dimension %d (16, 32, 64, 128 or 256)", hd);
+    MPO_CHECK(mpo_bag_sa_supported_head_dim(hd), "bag self-attention: head dimension %d (16, 32, 64, 128, 256 or 512)", hd);
     MPO_CHECK(map == nullptr || H == 1, "bag self-attention: the M x M map is returned for one head only (heads=%d)", H);
     MPO_CHECK(sa_al16(qkv) && sa_al16(o) && sa_al16(saved) && (map == nullptr || sa_al16(map)), "bag self-attention: buffers must be 16-byte aligned");
     float* lse2 = saved;
@@ -1131,6 +1147,7 @@ int mpo_launch_bag_sa_fwd(const float* qkv, int n_seq, int M, int d, int H, floa
         case 32: return sa_forward<32>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
         case 64: return sa_forward<64>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
         case 128: return sa_forward<128>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
+        case 512: return sa_forward<512>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
         default: return sa_forward<256>(qkv, n_seq, M, d, H, drop_p, seed, offset, epoch, o, lse2, map, s);
     }
 }
@@ -1141,7 +1158,7 @@ int mpo_launch_bag_sa_bwd(const float* qkv, const float* o, const float* saved, 
     MPO_CHECK(n_seq >= 1 && M >= 1 && H >= 1 && d % H == 0, "bag self-attention: %d sequences of %d rows, d=%d, heads=%d", n_seq, M, d, H);
     MPO_CHECK(n_seq <= 65535 && H <= 65535, "bag self-attention: %d sequences x %d heads exceed the grid", n_seq, H);
     const int hd = d / H;
-    MPO_CHECK(mpo_bag_sa_supported_head_dim(hd), "bag self-attention: head dimension %d (16, 32, 64, 128 or 256)", hd);
+    MPO_CHECK(mpo_bag_sa_supported_head_dim(hd), "bag self-attention: head dimension %d (16, 32, 64, 128, 256 or 512)", hd);
     MPO_CHECK(sa_al16(qkv) && sa_al16(o) && sa_al16(d_o) && sa_al16(dqkv) && sa_al16(saved) && sa_al16(scratch),
               "bag self-attention: buffers must be 16-byte aligned");
     const float* lse2 = saved;
@@ -1155,6 +1172,7 @@ int mpo_launch_bag_sa_bwd(const float* qkv, const float* o, const float* saved, 
         case 32: return sa_backward<32>(qkv, o, lse2, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, delta, s);
         case 64: return sa_backward<64>(qkv, o, lse2, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, delta, s);
         case 128: return sa_backward<128>(qkv, o, lse2, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, delta, s);
+        case 512: return sa_backward<512>(qkv, o, lse2, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, delta, s);
         default: return sa_backward<256>(qkv, o, lse2, d_o, n_seq, M, d, H, drop_p, seed, offset, epoch, dqkv, delta, s);
     }
 }

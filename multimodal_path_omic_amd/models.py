@@ -225,10 +225,6 @@ class GeneExprNarrowContextualAttentionGateTransformer(nn.Module):
     def __init__(self, model_size: str = "medium", n_classes: int = 3, dropout: float = 0.25,
                  bag_dtype: torch.dtype = torch.float32):
         super().__init__()
-        if model_size == "big":
-            # refused here, not at the first forward
-            raise NotImplementedError("GeneExprNarrowContextualAttentionGateTransformer(model_size='big') (one attention head of "
-                                      "512) is not built: the bag self-attention kernels cover head dimensions 16..256")
         self.model_sizes = MODEL_SIZES[model_size]
         d0, d1 = self.model_sizes
         self.bag_dtype = bag_dtype

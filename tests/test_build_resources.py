@@ -19,6 +19,7 @@ ALLOWED = {
     "coattn_bwd_kernelILi512ELb1": 4096,
     "coattn_bwd_kernelILi256ELb1": 1024,
     "key_proj_kernel": 32,
+    "bag_sa_bwd_dkv_kernelILi512": 16,               # one loop-invariant register (functional shape, model_size='big')
 }
 
 

@@ -42,7 +42,8 @@ def attention_ref(qkv, heads, keep=None):
 
 CASES = [  # n_bags, M, d, heads, q gain
     (1, 333, 256, 1, 1.0), (1, 1000, 256, 8, 1.0), (2, 64, 256, 8, 1.0), (1, 70, 128, 1, 1.0), (1, 130, 128, 8, 1.0),
-    (1, 200, 512, 8, 1.0), (1, 257, 256, 1, 6.0), (1, 515, 256, 8, 6.0), (1, 1, 256, 8, 1.0), (1, 17, 256, 1, 1.0)]
+    (1, 200, 512, 8, 1.0), (1, 257, 256, 1, 6.0), (1, 515, 256, 8, 6.0), (1, 1, 256, 8, 1.0), (1, 17, 256, 1, 1.0),
+    (1, 150, 512, 1, 1.0), (2, 333, 512, 1, 6.0)]      # one head of 512 (model_size='big'): dK / dV in two column passes
 
 
 def _b3_modes(d, heads):
@@ -115,7 +116,7 @@ def _recover_keep(dev, qkv, heads, p, offset):
     return keep
 
 
-@pytest.mark.parametrize("m,d,heads", [(96, 256, 8), (200, 256, 1)])
+@pytest.mark.parametrize("m,d,heads", [(96, 256, 8), (200, 256, 1), (70, 512, 1)])
 def test_attention_dropout_mask_is_shared_by_forward_and_backward(dev, m, d, heads):
     """Dropout on the probabilities: the mask is never stored.  It is read back here through identity-block values, must be
     {0, 1/(1-p)} at the stated rate, and a torch restatement using exactly that mask must reproduce the forward and all
@@ -274,13 +275,15 @@ def test_ge_model_training_step_at_15000_rows(dev):
         assert float(prm.grad.abs().max()) > 0, n
 
 
-def test_ge_model_small_equals_oracle_and_big_is_refused(dev):
-    """model_size='small' (embed 128: head dimensions 128 and 16) against the oracle; 'big' (one head of 512) is refused at
-    construction, and by the attention kernels with a message -- not run some other way."""
+@pytest.mark.parametrize("size,d", [("small", 128), ("big", 512)])
+def test_ge_model_small_and_big_equal_oracle(dev, size, d):
+    """model_size='small' (embed 128: head dimensions 128 and 16) and 'big' (embed 512: one head of 512, eight of 64;
+    models/ge_nacagat/ge_nacagat.py:12-17) against the oracle; a head dimension the kernels are not built for is refused
+    with a message -- not run some other way."""
     m, seed = 300, 4545
-    shapes = C.ge_model_shapes(d=128)
+    shapes = C.ge_model_shapes(d=d)
     sd = syn.fill_state_dict(shapes, seed)
-    model = GeneExprNarrowContextualAttentionGateTransformer(model_size="small")
+    model = GeneExprNarrowContextualAttentionGateTransformer(model_size=size)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     wsi, target = C.ge_model_inputs(m, seed + 1)
@@ -296,8 +299,6 @@ def test_ge_model_small_equals_oracle_and_big_is_refused(dev):
         ref = p[n].grad
         scale = max(float(ref.abs().max()), 1e-5)
         assert float((prm.grad.cpu() - ref).abs().max()) / scale < 5e-3, n
-    with pytest.raises(NotImplementedError, match="big"):
-        GeneExprNarrowContextualAttentionGateTransformer(model_size="big")
-    qkv = torch.zeros(1, 32, 3 * 512, device=dev)
-    with pytest.raises(RuntimeError, match="head dimension 512"):
+    qkv = torch.zeros(1, 32, 3 * 96, device=dev)
+    with pytest.raises(RuntimeError, match="head dimension 96"):
         ops.BagSelfAttentionFn.apply(qkv, 1, 0.0, True)

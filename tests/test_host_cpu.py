@@ -102,8 +102,8 @@ def test_c_index_vectorised_equals_oracle_loop():
 
 
 def test_model_sizes_of_the_reference_construct():
-    """small / medium / big (models/mcat/mcat.py:16-21, models/nacagat/nacagat.py:13-18) for both fusion models; the one size
-    still refused is the gene-expression model's 'big' (one attention head of 512 over the bag's rows), at construction."""
+    """small / medium / big (models/mcat/mcat.py:16-21, models/nacagat/nacagat.py:13-18, models/ge_nacagat/ge_nacagat.py:12-17)
+    construct for all three models."""
     from multimodal_path_omic_amd.models import (GeneExprNarrowContextualAttentionGateTransformer,
                                                  MultimodalCoAttentionTransformer,
                                                  NarrowContextualAttentionGateTransformer)
@@ -111,8 +111,8 @@ def test_model_sizes_of_the_reference_construct():
         for cls in (MultimodalCoAttentionTransformer, NarrowContextualAttentionGateTransformer):
             m = cls(omic_sizes=[8] * 6, model_size=size)
             assert tuple(m.co_attention.in_proj_weight.shape) == (3 * d, d)
-    with pytest.raises(NotImplementedError, match="big"):
-        GeneExprNarrowContextualAttentionGateTransformer(model_size="big")
+        ge = GeneExprNarrowContextualAttentionGateTransformer(model_size=size)
+        assert tuple(ge.self_attention.in_proj_weight.shape) == (3 * d, d) and tuple(ge.H[0].weight.shape) == (d, 1024)
 
 
 def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
