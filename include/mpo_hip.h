@@ -190,6 +190,14 @@ int mpo_set_gemm_fast_path(int enabled);
  * enabled = 0 sends every geometry through the general kernel.  Returns the previous setting (default 1).  ABI v11. */
 int mpo_set_coattn_bwd_two_wave(int enabled);
 
+/* K2 backward (models/blocks.py:184-187 differentiated): the query-side column accumulations  W1 K  and  W2 tanh(K)  and the
+ * bag-side  dK  both need the fp32 key bag and the two gradient maps and nothing of each other; for n_q <= 6 at embed <= 256
+ * ONE pass over K produces all three, on the vector ALUs in plain fp32 (bag_key_grad_kernel: with six queries the products
+ * are too skinny for the matrix pipe).  enabled = 0 restores the two passes on the matrix pipe (bag_colacc_gated, then
+ * bag_outer_gated; also what n_q > 6 and embed 512 run) as the check of the fused pass.  Returns the previous setting
+ * (default 1).  ABI v12. */
+int mpo_set_nacagat_one_pass_key_grad(int enabled);
+
 /* rng_epoch += 1 and adam_step += 1 (either may be NULL) in one launch: the per-step device counters of a captured
  * training step (dropout epoch of every mpo_*_forward, step count of mpo_adam_step_flat). */
 int mpo_step_counters_bump(uint64_t* rng_epoch, int32_t* adam_step, mpo_stream_t stream);

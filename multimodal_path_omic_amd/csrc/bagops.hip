@@ -819,6 +819,205 @@ void bag_outer_gated_kernel(const float* __restrict__ kbag, const int* __restric
     }
 }
 
+// (ii' + iii') for N <= 6 queries, ONE pass over K on the vector ALUs:
+//   part1[n][e] = sum_m W1[n][m] K[m][e],   part2[n][e] = sum_m W2[n][m] tanh(K[m][e])          (the query-side gradient)
+//   dK[m][e]    = sum_n W1[n][m] Z1[n][e] + (sum_n W2[n][m] Z2[n][e]) (1 - tanh(K[m][e])^2)     (+ its column sums)
+// Both need K and the two maps and nothing of each other.  With six queries every product is SKINNY: per element of K
+// 12 FMAs for dK and 12 for the accumulations -- as rank-6 MFMA work (k = 32 slots, six used, three split terms each) the
+// same dK costs 96 matrix instructions per 16 rows, twice the cycles of the plain FMAs, and needs K staged through an LDS
+// image to change layout.  Here a lane keeps its 4 columns: K arrives as one float4 per row (a wave reads whole rows),
+// tanh is evaluated once, Z1 / Z2 / the accumulators of the lane's columns sit in registers, the step's map columns are
+// published to a 1 KB per-wave LDS table and read back as broadcasts, dK leaves as one 8-byte (bf16) store per row.
+// No image, no fragments, no matrix pipe: 220 registers, so 8 waves per workgroup (two per SIMD) cover each other's
+// waits; the K rows of the next 16-row step are requested into the register a row has just left (ring of 16, distance
+// 16 rows).  737 MB per 32 x 15 000 window in 146 us (5.06 TB/s) against 127 + 152 us for the two matrix-pipe passes; the
+// same fusion on the image / MFMA kernel measured 213 us (the vector work of both passes behind one wave per SIMD).
+// The ragged last step of a row range is a plain loop (predicated stores inside the unrolled ring made the compiler spill
+// several hundred registers across its sixteen exec-mask branches).
+template <int E_, bool OUT_BF16, int NQA>
+__global__ __launch_bounds__(512, 1)
+void bag_key_grad_kernel(const float* __restrict__ kbag, const int* __restrict__ cu, const float* __restrict__ w1,
+                         const float* __restrict__ z1, const float* __restrict__ w2, const float* __restrict__ z2,
+                         void* __restrict__ dk, float* __restrict__ part_colsum /* nullable [parts][E] */,
+                         float* __restrict__ part1, float* __restrict__ part2, int n_q, BagPlan plan) {
+    constexpr int WAVES = 8;
+    constexpr int HR = 16;                                   // rows per step
+    constexpr int CH_PER_ROW = E_ / 4;                       // 16-byte chunks per fp32 row
+    constexpr int RPP = 64 / CH_PER_ROW;                     // rows a wave covers with one float4 per lane (1 at E = 256)
+    constexpr int NCH = HR / RPP;                            // float4 per lane per step
+    constexpr int WTAB = 2 * HR * 8;                         // floats per wave: [map][row][8 queries]
+    static_assert(NQA >= 1 && NQA <= 8 && 64 % CH_PER_ROW == 0 && CH_PER_ROW <= 64, "geometry");
+    constexpr int RED = 2 * 8 * E_ + E_;                     // per wave: [product][8][E] + [E] column sums
+    __shared__ __attribute__((aligned(16))) float lds[WAVES * WTAB + WAVES * RED];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SplitGeom sg = split_geom<WAVES>(cu, plan, wave);
+    float* wt = lds + wave * WTAB;
+    float* red = lds + WAVES * WTAB + wave * RED;
+    const int cc = lane % CH_PER_ROW, rs = lane / CH_PER_ROW;
+    const int b = sg.b;
+    // the lane's columns of Z1 / Z2 (rows n >= n_q: any finite value, their map columns are zero)
+    f32x4 zz1[NQA], zz2[NQA];
+#pragma unroll
+    for (int n = 0; n < NQA; ++n) {
+        const int qc = n < n_q ? n : n_q - 1;
+        zz1[n] = *reinterpret_cast<const f32x4*>(z1 + ((size_t)b * n_q + qc) * E_ + 4 * cc);
+        zz2[n] = *reinterpret_cast<const f32x4*>(z2 + ((size_t)b * n_q + qc) * E_ + 4 * cc);
+    }
+    f32x4 acc1[NQA], acc2[NQA];
+#pragma unroll
+    for (int n = 0; n < NQA; ++n) { acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[n] = acc1[n]; }
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    const float* w1b = w1 + (size_t)n_q * sg.row_begin;
+    const float* w2b = w2 + (size_t)n_q * sg.row_begin;
+    const float* kslide = kbag + (size_t)sg.row_begin * E_;
+    char* dslide = reinterpret_cast<char*>(dk) + (size_t)sg.row_begin * E_ * (OUT_BF16 ? 2 : 4);
+    auto step_row = [&](int st) { return sg.r0 + kTileRows * (wave + (st >> 1) * WAVES) + HR * (st & 1); };
+    const int n_steps = 2 * sg.n_my;
+    // map columns of a step: lane (m = lane & 15, quarter = lane >> 4) holds queries quarter and quarter + 4
+    const int tm = lane & 15, tq = lane >> 4;
+    float wn[4];                                             // W1[tq], W1[tq + 4], W2[tq], W2[tq + 4] at row tm of the NEXT step
+    auto fetch_maps = [&](int st) {
+        st = st < n_steps ? st : n_steps - 1;
+        const int row0 = step_row(st);
+        int mrow = row0 + tm;
+        const bool live = mrow < sg.r1;
+        mrow = mrow < sg.m_rows ? mrow : sg.m_rows - 1;
+        const int qa = tq < n_q ? tq : n_q - 1, qb = tq + 4 < n_q ? tq + 4 : n_q - 1;
+        const float a0 = w1b[(size_t)qa * sg.m_rows + mrow], a1 = w1b[(size_t)qb * sg.m_rows + mrow];
+        const float b0 = w2b[(size_t)qa * sg.m_rows + mrow], b1 = w2b[(size_t)qb * sg.m_rows + mrow];
+        wn[0] = live && tq < n_q ? a0 : 0.f;
+        wn[1] = live && tq + 4 < n_q ? a1 : 0.f;
+        wn[2] = live && tq < n_q ? b0 : 0.f;
+        wn[3] = live && tq + 4 < n_q ? b1 : 0.f;
+    };
+    f32x4 kv[NCH];
+    auto fetch_row = [&](int st, int i) {
+        st = st < n_steps ? st : n_steps - 1;
+        int grow = step_row(st) + i * RPP + rs;
+        grow = grow < sg.m_rows ? grow : sg.m_rows - 1;
+        kv[i] = *reinterpret_cast<const f32x4*>(kslide + (size_t)grow * E_ + 4 * cc);
+    };
+    // one row (r of the step, K values k) of the lane's 4 columns
+    auto row_math = [&](int r, const f32x4& k, f32x4& o) {
+        const f32x4 t = {fast_tanh(k[0]), fast_tanh(k[1]), fast_tanh(k[2]), fast_tanh(k[3])};
+        const f32x4 wa0 = *reinterpret_cast<const f32x4*>(wt + (0 * HR + r) * 8);
+        const f32x4 wb0 = *reinterpret_cast<const f32x4*>(wt + (1 * HR + r) * 8);
+        f32x4 wa1 = wa0, wb1 = wb0;
+        if constexpr (NQA > 4) {
+            wa1 = *reinterpret_cast<const f32x4*>(wt + (0 * HR + r) * 8 + 4);
+            wb1 = *reinterpret_cast<const f32x4*>(wt + (1 * HR + r) * 8 + 4);
+        }
+        f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = u;
+#pragma unroll
+        for (int n = 0; n < NQA; ++n) {
+            const float a = n < 4 ? wa0[n & 3] : wa1[n & 3], bb = n < 4 ? wb0[n & 3] : wb1[n & 3];
+            acc1[n] += k * a;
+            acc2[n] += t * bb;
+            u += zz1[n] * a;
+            v += zz2[n] * bb;
+        }
+        o = u + v * (1.0f - t * t);
+    };
+    auto row_store = [&](int grow, const f32x4& o) {
+        if constexpr (OUT_BF16) {
+            const bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+            *reinterpret_cast<bf16x4*>(dslide + ((size_t)grow * E_ + 4 * cc) * 2) = ob;
+            csum += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};      // what the caller will sum
+        } else {
+            *reinterpret_cast<f32x4*>(dslide + ((size_t)grow * E_ + 4 * cc) * 4) = o;
+            csum += o;
+        }
+    };
+    auto publish_maps = [&](int st) {
+        wt[(0 * HR + tm) * 8 + tq] = wn[0];
+        wt[(0 * HR + tm) * 8 + tq + 4] = wn[1];
+        wt[(1 * HR + tm) * 8 + tq] = wn[2];
+        wt[(1 * HR + tm) * 8 + tq + 4] = wn[3];
+        fetch_maps(st + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // a step whose 16 rows all exist: nothing is predicated, the register ring runs
+    auto step = [&](int st) {
+        const int row0 = step_row(st);
+        publish_maps(st);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int r = i * RPP + rs;
+            const f32x4 k = kv[i];
+            fetch_row(st + 1, i);                               // the register is free again: next step's row i
+            f32x4 o;
+            row_math(r, k, o);
+            row_store(row0 + r, o);
+            __builtin_amdgcn_sched_barrier(0);                  // one row's working set at a time (the scheduler otherwise hoists all 16)
+        }
+        __builtin_amdgcn_wave_barrier();                        // the table is rewritten by the next step
+    };
+    // the ragged last step(s) of a range: a plain loop over the rows that exist, each loaded where it is used (the ring's
+    // requests for these steps were clamped into the slide and are dropped)
+    auto ragged_step = [&](int st) {
+        const int row0 = step_row(st);
+        const int nvalid = max(0, min(HR, sg.r1 - row0));
+        publish_maps(st);
+        for (int r = rs; r < nvalid; r += RPP) {
+            const f32x4 k = *reinterpret_cast<const f32x4*>(kslide + (size_t)(row0 + r) * E_ + 4 * cc);
+            f32x4 o;
+            row_math(r, k, o);
+            row_store(row0 + r, o);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (n_steps > 0) {
+        int n_full = 0;
+        while (n_full < n_steps && step_row(n_full) + HR <= sg.r1) ++n_full;
+        fetch_maps(0);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) fetch_row(0, i);
+        int st = 0;
+        for (; st < n_full; ++st) step(st);
+        for (; st < n_steps; ++st) ragged_step(st);
+    }
+    // lanes l, l + CH_PER_ROW, ... hold the same column chunk (other rows); then the four waves through LDS in a fixed order
+#pragma unroll
+    for (int o = CH_PER_ROW; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            csum[j] += __shfl_xor(csum[j], o);
+#pragma unroll
+            for (int n = 0; n < NQA; ++n) { acc1[n][j] += __shfl_xor(acc1[n][j], o); acc2[n][j] += __shfl_xor(acc2[n][j], o); }
+        }
+    }
+    if (lane < CH_PER_ROW) {
+#pragma unroll
+        for (int n = 0; n < NQA; ++n) {
+            *reinterpret_cast<f32x4*>(red + (0 * 8 + n) * E_ + 4 * lane) = acc1[n];
+            *reinterpret_cast<f32x4*>(red + (1 * 8 + n) * E_ + 4 * lane) = acc2[n];
+        }
+        *reinterpret_cast<f32x4*>(red + 2 * 8 * E_ + 4 * lane) = csum;
+    }
+    __syncthreads();
+    const float* all = lds + WAVES * WTAB;
+    for (int idx = threadIdx.x; idx < n_q * E_; idx += WAVES * 64) {
+        const int n = idx / E_, e = idx % E_;
+        float a = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            a += all[w * RED + (0 * 8 + n) * E_ + e];
+            bsum += all[w * RED + (1 * 8 + n) * E_ + e];
+        }
+        part1[(size_t)sg.part * n_q * E_ + idx] = a;
+        part2[(size_t)sg.part * n_q * E_ + idx] = bsum;
+    }
+    if (part_colsum != nullptr)
+        for (int idx = threadIdx.x; idx < E_; idx += WAVES * 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) a += all[w * RED + 2 * 8 * E_ + idx];
+            part_colsum[(size_t)sg.part * E_ + idx] = a;
+        }
+}
+
 // ------------------------------------------------------------------ map kernels (one workgroup per (query, slide))
 constexpr int kMapThreads = 512;                               // 8 waves per (query, slide) row
 __device__ __forceinline__ float block_max(float v, float* red) {
@@ -1286,6 +1485,26 @@ int mpo_launch_bag_colacc_gated(const void* bag, int bag_f32, const int* cu, int
     } else {
         MPO_E_SWITCH(embed, (bag_colacc_gated_kernel<EV, false><<<grid, BagCfg<EV, false>::WAVES * 64, 0, stream>>>(bag, cu, w1map, w2map, part1, part2, n_q, plan)))
     }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int mpo_launch_bag_key_grad(const float* kbag, const int* cu, int n_slides, int embed, const float* w1, const float* z1,
+                            const float* w2, const float* z2, void* dk, int dk_f32, float* part_colsum, float* part1,
+                            float* part2, int n_q, const BagPlan& plan, hipStream_t stream) {
+    (void)n_slides;
+    dim3 grid = plan_grid(plan);
+    if (part1 == nullptr || part2 == nullptr || n_q < 1 || n_q > 6) {
+        mpo_set_error("bag key-gradient pass: needs both partial buffers and 1 <= n_q <= 6 (got %d)", n_q);
+        return 1;
+    }
+#define MPO_KG(F32OUT, NQA_) MPO_E_SWITCH(embed, (bag_key_grad_kernel<EV, !(F32OUT), NQA_><<<grid, 512, 0, stream>>>(kbag, cu, w1, z1, w2, z2, dk, part_colsum, part1, part2, n_q, plan)))
+    if (n_q <= 4) {
+        if (dk_f32) { MPO_KG(true, 4) } else { MPO_KG(false, 4) }
+    } else {
+        if (dk_f32) { MPO_KG(true, 6) } else { MPO_KG(false, 6) }
+    }
+#undef MPO_KG
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -35,6 +35,10 @@ struct Arena {
 };
 static inline size_t arena_need(size_t acc, size_t n_floats) { return align_up(acc, 256) + n_floats * 4; }
 
+namespace {
+bool g_k2_one_pass_key = true;     // K2 backward: the whole key gradient in one pass over K (bag_key_grad_kernel; mpo_set_nacagat_one_pass_key_grad)
+}
+
 // ONE workgroup per CU over the window (256 CUs): long row ranges amortise the per-workgroup prologue
 // (query fragments) and epilogue (LDS merge, partial write); measured r01 on 32 x 15k bf16:
 // 256 WGs 51.6 us, 512 59.0, 1024 73.0, 2048 98.9.
@@ -79,7 +83,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 11; }
+int mpo_abi_version(void) { return 12; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -522,8 +526,10 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     if ((rc = mpo_launch_gated_softmax_bwd(a_map, g_map, cu_rows, lse2, dasum, d_attn_map, ds1_map, dg_map, n_slides, n_q,
                                            drop_p, seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), stream))) return rc;
     // query side: dq~ = ds1 K, dtq = dg TK
-    // (one pass over K, tanh on the fly)
-    for (int h = 0; h < NH; ++h) {
+    // (one pass over K, tanh on the fly) -- or, for N <= 6 at embed <= 256, out of the bag-side pass below: both need K and
+    // the two maps and nothing of each other, so K (491 MB per 32 x 15 000 window) is read once for the two
+    const bool one_pass = g_k2_one_pass_key && NH == 1 && n_q <= 6;
+    for (int h = 0; h < NH && !one_pass; ++h) {
         if ((rc = mpo_launch_bag_colacc_gated(static_cast<const char*>(kbag) + h * half_k, 1, cu_rows, n_slides, EH, ds1_map, dg_map,
                                               part, part2, n_q, splits, stream))) return rc;
         BagFinish f{};
@@ -534,9 +540,13 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
             if ((rc = copy_cols(dtq + h * EH, E, hb[3], EH, R, EH, stream))) return rc;
         }
     }
-    if ((rc = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream))) return rc;
-    if ((rc = mpo_linear_bwd_pair(mpo_args_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0),
-                                  mpo_args_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f), stream))) return rc;
+    auto query_side = [&]() -> int {
+        if (int r = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream)) return r;
+        return mpo_linear_bwd_pair(mpo_args_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0),
+                                   mpo_args_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f), stream);
+    };
+    if (!one_pass)
+        if ((rc = query_side())) return rc;
     // bag side: dK = ds1^T q~ + (dg^T tq) * (1 - TK^2),  dH = A_drop^T dctx
     // (one pass: tanh' from the staged K tile)
     for (int h = 0; h < NH; ++h) {
@@ -546,7 +556,10 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
             if ((rc = copy_cols(hb[5], EH, tq + h * EH, E, R, EH, stream))) return rc;
             qth = hb[4]; tqh = hb[5];
         }
-        if ((rc = mpo_launch_bag_outer_gated(reinterpret_cast<const float*>(static_cast<const char*>(kbag) + h * half_k), cu_rows,
+        if (one_pass) {
+            if ((rc = mpo_launch_bag_key_grad(reinterpret_cast<const float*>(kbag), cu_rows, n_slides, EH, ds1_map, qth, dg_map, tqh,
+                                              d_kbag, dk_dtype == MPO_F32, part_cs, part, part2, n_q, splits, stream))) return rc;
+        } else if ((rc = mpo_launch_bag_outer_gated(reinterpret_cast<const float*>(static_cast<const char*>(kbag) + h * half_k), cu_rows,
                                              n_slides, EH, ds1_map, qth, dg_map, tqh, static_cast<char*>(d_kbag) + h * half_dk,
                                              dk_dtype == MPO_F32, part_cs, n_q, splits, stream))) return rc;
         // one launch: the key bag's column sums, and (first half) zeros for the key slice of the packed in-projection (it
@@ -557,8 +570,11 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
             f.zero[0] = d_in_w + (size_t)E * E; f.n_zero[0] = E * E;
             if (d_kbag_colsum != d_in_b + E) { f.zero[1] = d_in_b + E; f.n_zero[1] = E; }
         }
+        if (one_pass) { f.part[0] = part; f.out[0] = dqt; f.part[1] = part2; f.out[1] = dtq; f.n_red = 2; }
         if ((rc = mpo_launch_bag_finish(f, n_slides, n_q, EH, splits, stream))) return rc;
     }
+    if (one_pass)
+        if ((rc = query_side())) return rc;
     if (d_ctx == nullptr)
         for (int h = 0; h < NH; ++h)
             if ((rc = mpo_launch_bag_outer(cu_rows, n_slides, EH, attn_map, NH > 1 ? hb[h] : dctx, nullptr, nullptr,
@@ -701,6 +717,12 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
 // give the same bits.  enabled = 0 routes every product through the general body.  Returns the previous setting.
 int mpo_set_gemm_fast_path(int enabled) { return mpo_gemm_fast_path(enabled); }
 int mpo_set_coattn_bwd_two_wave(int enabled) { return mpo_coattn_bwd8_enable(enabled); }
+// verification hook: 0 = K2's backward reads K twice (bag_colacc_gated, then bag_outer_gated, both on the matrix pipe) as in rounds 1-2
+int mpo_set_nacagat_one_pass_key_grad(int enabled) {
+    const int was = g_k2_one_pass_key ? 1 : 0;
+    g_k2_one_pass_key = enabled != 0;
+    return was;
+}
 
 // The two device-resident per-step counters of a captured training step, bumped by one launch.
 int mpo_step_counters_bump(uint64_t* rng_epoch, int32_t* adam_step, mpo_stream_t stream) {

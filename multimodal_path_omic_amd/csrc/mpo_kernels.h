@@ -305,6 +305,9 @@ int mpo_launch_bag_colacc_gated(const void* bag, int bag_f32, const int* cu, int
 int mpo_launch_bag_outer_gate(const int* cu, int n_slides, int embed, const float* w1, const float* z1, const void* addend,
                               const void* hbag, void* out, float gate, float* part_colsum, int n_q, const BagPlan& plan,
                               hipStream_t stream);
+int mpo_launch_bag_key_grad(const float* kbag, const int* cu, int n_slides, int embed, const float* w1, const float* z1,
+                            const float* w2, const float* z2, void* dk, int dk_f32, float* part_colsum, float* part1,
+                            float* part2, int n_q, const BagPlan& plan, hipStream_t stream);
 int mpo_launch_bag_outer_gated(const float* kbag, const int* cu, int n_slides, int embed, const float* w1, const float* z1,
                                const float* w2, const float* z2, void* dk, int dk_f32, float* part_colsum /* nullable */,
                                int n_q, const BagPlan& plan, hipStream_t stream);

@@ -111,6 +111,35 @@ def test_nacagat_forward_backward(dev, golden, case, dtype):
             assert relerr(sub(gr), ref) < (6e-3 if peaky else 3e-3), (n, relerr(sub(gr), ref))
 
 
+@pytest.mark.parametrize("case", list(C.NACAGAT_CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_one_pass_key_gradient_equals_the_two_pass_order(dev, case, dtype):
+    """K2 backward: the query-side column accumulations out of the bag-side pass over K (csrc/bagops.hip,
+    bag_key_grad_kernel: plain fp32 FMAs on the vector ALUs) against the two separate passes (three-term bf16 MFMA) -- same maps,
+    same K, so every gradient agrees to fp32 accumulation noise."""
+    from multimodal_path_omic_amd import _lib as L
+    m, gain, seed = C.NACAGAT_CASES[case]
+    q, bag, p_out, p_a = C.coattn_inputs(m, seed + 1)
+    got = []
+    for one_pass in (1, 0):
+        prev = L.lib().mpo_set_nacagat_one_pass_key_grad(one_pass)
+        try:
+            mod, p = make_module(seed, gain, dev)
+            mod.eval()
+            qd = q.to(dev).requires_grad_(True)
+            bd = bag.to(dtype).to(dev).requires_grad_(True)
+            out, a = mod(query=qd, key=bd, value=bd)
+            params = dict(mod.named_parameters())
+            tensors = [qd, bd] + [params[k[len("co_attention."):]] for k in p]
+            got.append(torch.autograd.grad((out * p_out.to(dev)).sum() + (a * p_a.to(dev)).sum(), tensors))
+        finally:
+            L.lib().mpo_set_nacagat_one_pass_key_grad(prev)
+    names = ["query", "bag"] + list(p)
+    for n, g1, g0 in zip(names, *got):
+        # a bf16 bag takes d_bag in bf16: a last-bit difference in dK moves single elements by one bf16 ulp
+        assert relerr(g1, g0) < (4e-3 if g1.dtype == torch.bfloat16 else 2e-5), (n, relerr(g1, g0))
+
+
 def test_nacagat_training_dropout_replays_through_oracle(dev):
     """Training mode: the returned map is post-dropout (models/blocks.py:189-190,206).  The mask is
     recovered from the map (A > 0 everywhere before dropout) and replayed through the oracle."""
