@@ -136,8 +136,12 @@ def test_one_pass_key_gradient_equals_the_two_pass_order(dev, case, dtype):
             L.lib().mpo_set_nacagat_one_pass_key_grad(prev)
     names = ["query", "bag"] + list(p)
     for n, g1, g0 in zip(names, *got):
-        # a bf16 bag takes d_bag in bf16: a last-bit difference in dK moves single elements by one bf16 ulp
-        assert relerr(g1, g0) < (4e-3 if g1.dtype == torch.bfloat16 else 2e-5), (n, relerr(g1, g0))
+        # fp32: the two-pass order carries the three-term split's ~2^-17 per product, the one-pass kernel plain fp32.  A bf16
+        # bag takes dK and d_bag in bf16: that difference flips the rounding of ~2e-3 of the elements by one bf16 ulp (d_bag),
+        # and the key projection's dW_k = dK^T H sums the flips (measured 1.4e-4 .. 1.2e-3; the bar against the oracle is
+        # GRAD_TOL_BF16_PARAM and both orders hold it in test_nacagat_forward_backward)
+        tol = 2e-5 if dtype == torch.float32 else (4e-3 if n == "bag" else GRAD_TOL_BF16_PARAM)
+        assert relerr(g1, g0) < tol, (n, relerr(g1, g0))
 
 
 def test_nacagat_training_dropout_replays_through_oracle(dev):
