@@ -190,6 +190,12 @@ int mpo_set_gemm_fast_path(int enabled);
  * enabled = 0 sends every geometry through the general kernel.  Returns the previous setting (default 1).  ABI v11. */
 int mpo_set_coattn_bwd_two_wave(int enabled);
 
+/* K1 backward of an fp32-stored bag (embed 256, n_q <= 8, no map gradient) runs on the vector ALUs in plain fp32
+ * (csrc/coattn_bwd_f32.hip: with six queries every product is skinny; the matrix-pipe kernel needs split images, both
+ * orientations and 1 KB of scratch per lane for the same result).  enabled = 0 sends fp32 bags through the general kernel as
+ * the check of this one.  Returns the previous setting (default 1).  ABI v12. */
+int mpo_set_coattn_bwd_f32_vector(int enabled);
+
 /* K2 backward (models/blocks.py:184-187 differentiated): the query-side column accumulations  W1 K  and  W2 tanh(K)  and the
  * bag-side  dK  both need the fp32 key bag and the two gradient maps and nothing of each other; for n_q <= 6 at embed <= 256
  * ONE pass over K produces all three, on the vector ALUs in plain fp32 (bag_key_grad_kernel: with six queries the products

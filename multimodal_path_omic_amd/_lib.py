@@ -105,6 +105,7 @@ _SIGNATURES = {
     "mpo_set_gemm_fast_path": (c_int, [c_int]),
     "mpo_set_coattn_bwd_two_wave": (c_int, [c_int]),
     "mpo_set_nacagat_one_pass_key_grad": (c_int, [c_int]),
+    "mpo_set_coattn_bwd_f32_vector": (c_int, [c_int]),
     "mpo_omic_snn_saved_floats": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_workspace_bytes": (c_size_t, [c_int] * 3),
     "mpo_omic_snn_rng_span": (c_uint64, [c_int] * 3),

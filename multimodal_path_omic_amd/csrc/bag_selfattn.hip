@@ -37,7 +37,9 @@ template <int HD> struct SaCfg {
 
 // Counter-based hash, not Philox: 32-bit integer multiplies run at a quarter of the vector rate on this chip, and the ten
 // Philox rounds (40 multiplies) of one block cost a third of the bf16 kernels' step.  One block = 16 bytes = four words, each
-// the murmur3 finaliser (two multiplies, full avalanche) of a key mixed with the block's coordinates.
+// the murmur3 finaliser (two multiplies, full avalanche) of a key mixed with the block's coordinates; the block's 32-bit
+// x is a bottleneck (at M = 15 000, ~2e4 of a head's 1.4e7 blocks repeat another block's 16 bytes) -- irrelevant to parity
+// (all three kernels regenerate the same mask), stated so that nobody takes the mask for 128 independent bits per block.
 __device__ __forceinline__ uint32_t sa_fmix(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
@@ -46,6 +48,8 @@ struct SaDrop {
     unsigned thr;                                            // keep when byte >= thr (0: no dropout)
     float inv_keep;
     uint32_t key;                                            // seed, stream offset (+ epoch) and head, hashed
+    uint32_t inc;                                            // odd word stride, also from the key: two keys' blocks are not
+                                                             // the same draws at permuted coordinates (mpo_common.h hash4x32)
 };
 __device__ __forceinline__ SaDrop sa_drop(float p, unsigned long long seed, unsigned long long offset,
                                           const unsigned long long* epoch, int head) {
@@ -59,6 +63,7 @@ __device__ __forceinline__ SaDrop sa_drop(float p, unsigned long long seed, unsi
     k = sa_fmix(k ^ (uint32_t)ctr);
     k = sa_fmix(k ^ (uint32_t)(ctr >> 32));
     d.key = sa_fmix(k ^ (uint32_t)head);
+    d.inc = sa_fmix(d.key ^ 0x9E3779B9u) | 1u;
     return d;
 }
 // the 16 bytes of block (q / 4, key / 4); element (q % 4, key % 4) is byte 4 * (q % 4) + key % 4
@@ -67,11 +72,11 @@ __device__ __forceinline__ uint32_t sa_block_x(const SaDrop& d, int qb, int kb) 
 }
 // word i (= q % 4) of the block alone: what the forward / dQ orientation needs (one query per lane)
 __device__ __forceinline__ uint32_t sa_block_word(const SaDrop& d, int qb, int kb, int i) {
-    return sa_fmix(sa_block_x(d, qb, kb) + (uint32_t)i * 0x27D4EB2Fu);
+    return sa_fmix(sa_block_x(d, qb, kb) + (uint32_t)i * d.inc);
 }
 __device__ __forceinline__ uint4 sa_block(const SaDrop& d, int qb, int kb) {
     const uint32_t x = sa_block_x(d, qb, kb);
-    return make_uint4(sa_fmix(x), sa_fmix(x + 0x27D4EB2Fu), sa_fmix(x + 2u * 0x27D4EB2Fu), sa_fmix(x + 3u * 0x27D4EB2Fu));
+    return make_uint4(sa_fmix(x), sa_fmix(x + d.inc), sa_fmix(x + 2u * d.inc), sa_fmix(x + 3u * d.inc));
 }
 __device__ __forceinline__ float sa_keep(const SaDrop& d, uint32_t word, int byte) {
     return ((word >> (8 * byte)) & 255u) >= d.thr ? d.inv_keep : 0.f;

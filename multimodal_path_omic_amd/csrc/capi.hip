@@ -717,6 +717,8 @@ int mpo_adam_step_flat(float* params, const float* grads, float* exp_avg, float*
 // give the same bits.  enabled = 0 routes every product through the general body.  Returns the previous setting.
 int mpo_set_gemm_fast_path(int enabled) { return mpo_gemm_fast_path(enabled); }
 int mpo_set_coattn_bwd_two_wave(int enabled) { return mpo_coattn_bwd8_enable(enabled); }
+// verification hook: 0 = fp32 bags take the general (matrix-pipe) K1 backward
+int mpo_set_coattn_bwd_f32_vector(int enabled) { return mpo_coattn_bwd_f32_enable(enabled); }
 // verification hook: 0 = K2's backward reads K twice (bag_colacc_gated, then bag_outer_gated, both on the matrix pipe) as in rounds 1-2
 int mpo_set_nacagat_one_pass_key_grad(int enabled) {
     const int was = g_k2_one_pass_key ? 1 : 0;

@@ -46,7 +46,8 @@ def test_no_unexpected_scratch(usage):
 def test_headline_kernels_are_register_resident(usage):
     """The kernels the bench line is made of (E=256, bf16 bag) must have no scratch and no spills at all."""
     hot = ["coattn_fwd_partial_kernelILi256ELb0", "coattn_bwd_kernelILi256ELb0", "coattn_bwd8_kernel", "bag_rowdot_gated_exact_kernelILi256E", "patch_coattn_fwd_kernel", "patch_wgrad_kernel",
-           "bag_colacc_gated_kernelILi256ELb1", "bag_outer_gated_kernelILi256ELb1", "bag_key_grad_kernelILi256ELb1ELi6", "gemm_f32_direct_kernelILi4",
+           "bag_colacc_gated_kernelILi256ELb1", "bag_outer_gated_kernelILi256ELb1", "bag_key_grad_kernelILi256ELb1ELi6",
+           "coattn_bwd_f32_kernel", "gemm_f32_direct_kernelILi4",
            "gemm_f32_direct_kernelILi8",
            # row f3: the three-term bf16 self-attention kernels of the medium model and the many-row GEMM forms
            "bag_sa_b3_fwd_kernelILi32E", "bag_sa_b3_dq_kernelILi32E", "bag_sa_b3_dkv_kernelILi32E", "bag_sa_b3_fwd_kernelILi256E",

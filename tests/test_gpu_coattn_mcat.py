@@ -6,6 +6,8 @@ For a bf16-stored bag the oracle is fed the same bf16-rounded values (bf16 is a 
 the INPUT; arithmetic stays fp32-accurate through hi/lo operand splitting), the bag gradient is
 rounded to bf16 by construction and gets a bf16-sized tolerance.
 """
+import math
+
 import pytest
 import torch
 
@@ -251,3 +253,57 @@ def test_two_wave_backward_equals_the_general_kernel(dev, n_q, gate):
     for k in dw1:
         if dw1[k] is not None:
             assert relerr(dw8[k], dw1[k]) < 1e-4 or float(dw1[k].abs().max()) < 1e-12, k
+
+
+@pytest.mark.parametrize("n_q", [1, 6, 8])
+def test_fp32_bag_vector_backward_equals_the_general_kernel_and_fp64(dev, n_q):
+    """K1 backward of an fp32 bag on the vector ALUs (csrc/coattn_bwd_f32.hip, plain fp32) against the general matrix-pipe kernel
+    (three-term split) on a ragged window -- one-row slides, rows around every tile / step boundary, several tiles per wave --
+    and both against a torch fp64 restatement of the folded co-attention (models/mcat/mcat.py:97): the vector kernel must
+    be at least as close."""
+    from multimodal_path_omic_amd import _lib as L
+    from multimodal_path_omic_amd import ops
+    lengths = [1, 15, 16, 17, 31, 32, 33, 255, 700, 3000, 5000]
+    g = syn.rng(177 + n_q)
+    sd = syn.fill_state_dict(C.MCAT_COATTN_SHAPES, 178)
+    p = {k[len("co_attention."):]: v.to(dev) for k, v in sd.items()}
+    bags = [syn.normal(g, (m, C.E)).to(dev) for m in lengths]
+    query = syn.normal(g, (len(lengths) * n_q, C.E)).to(dev)
+    probe = syn.normal(g, (len(lengths) * n_q, C.E)).to(dev)
+
+    def run(vector):
+        prev = L.lib().mpo_set_coattn_bwd_f32_vector(int(vector))
+        try:
+            batch = BagBatch.from_list(bags)
+            data = batch.data.detach().requires_grad_(True)
+            q = query.clone().requires_grad_(True)
+            w = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            out, _ = ops.coattn_mcat(q, batch.with_data(data), w["in_proj_weight"], w["in_proj_bias"], w["out_proj.weight"],
+                                     w["out_proj.bias"], False, 0.0)
+            (out * probe).sum().backward()
+            return data.grad, q.grad, {k: v.grad for k, v in w.items()}
+        finally:
+            L.lib().mpo_set_coattn_bwd_f32_vector(prev)
+    dbv, dqv, dwv = run(True)
+    dbm, dqm, dwm = run(False)
+    # fp64 restatement
+    e = C.E
+    w64 = {k: v.double().cpu().requires_grad_(True) for k, v in p.items()}
+    q64 = query.double().cpu().requires_grad_(True)
+    b64 = [b.double().cpu().requires_grad_(True) for b in bags]
+    wq, wk, wv = w64["in_proj_weight"][:e], w64["in_proj_weight"][e:2 * e], w64["in_proj_weight"][2 * e:]
+    bq, bk, bv = w64["in_proj_bias"][:e], w64["in_proj_bias"][e:2 * e], w64["in_proj_bias"][2 * e:]
+    outs = []
+    for i, hb in enumerate(b64):
+        qq = q64[i * n_q:(i + 1) * n_q] @ wq.T + bq
+        a = torch.softmax(qq @ (hb @ wk.T + bk).T / math.sqrt(e), dim=-1)
+        outs.append((a @ (hb @ wv.T + bv)) @ w64["out_proj.weight"].T + w64["out_proj.bias"])
+    (torch.cat(outs) * probe.double().cpu()).sum().backward()
+    db64 = torch.cat([b.grad for b in b64])
+    ev, em = relerr(dbv, db64), relerr(dbm, db64)
+    print(f"[K1 fp32 backward] n_q={n_q}: d_bag vs fp64: vector {ev:.2e}, matrix pipe {em:.2e}; query {relerr(dqv, q64.grad):.2e}")
+    assert ev < 2e-5 and ev <= em * 1.5 + 1e-6, (ev, em)
+    assert relerr(dqv, q64.grad) < 2e-5
+    for k in dwv:
+        assert relerr(dwv[k], w64[k].grad) < 5e-5, k
+    assert relerr(dbv, dbm) < 1e-4 and relerr(dqv, dqm) < 1e-4
