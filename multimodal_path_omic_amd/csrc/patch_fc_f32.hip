@@ -30,7 +30,7 @@
 // mask lives in H_bag as zeros, the backward reads it back from there), fp32 store.
 //
 // Weight gradient, 256 workgroups of 8 waves = 64 row ranges x 4 column blocks of X (256 columns each; the four blocks of a
-// range are neighbours in the grid, hence on one XCD: dH and H_bag are fetched from HBM once and shared through L2, as in
+// range sit on one XCD -- workgroup ids 8 apart --: dH and H_bag are fetched from HBM once and shared through L2, as in
 // patch_wgrad.hip): a 256 x 256 fp32 block of dW in registers (wave: 64 x 128, 128 accumulators), 32-row chunks: dH, H_bag
 // and X global -> registers one chunk ahead, gate + split, written TRANSPOSED-readable (row-major bf16 images read with
 // ds_read_b64_tr_b16), three MFMA terms; fp32 partials per row range + the reduction launch of patch_wgrad.hip.  The column
@@ -249,7 +249,13 @@ void patch_wgrad_f32_kernel(const float* __restrict__ dh,         // [rows][256]
     __shared__ __attribute__((aligned(1024))) char lds[2 * 4 * GIMG];        // [stage][g hi | g lo | x hi | x lo]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int range = blockIdx.x >> 2, cb = blockIdx.x & 3;
+    // workgroup id -> (row range, column block): the four column blocks of a row range read the same dH / H_bag rows and must
+    // share an L2, i.e. an XCD (blockIdx -> XCD is round-robin, id mod 8).  r03 PMC: with the blocks of a range on FOUR
+    // NEIGHBOURING ids (= four XCDs) the kernel fetched 9.90 GB per 8 x 100 000 window against 4.92 GB algorithmic -- every
+    // block its own copy of dH and H_bag (profiles/r03_pmc_mcat_f32_100k.json)
+    static_assert(GRANGES % 8 == 0, "row ranges are dealt to the 8 XCDs");
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int range = xcd + 8 * (slot >> 2), cb = slot & 3;
     const long long per = ((total_rows + GRANGES - 1) / GRANGES + GCH - 1) / GCH * GCH;
     const long long r0 = (long long)range * per, r1 = min(total_rows, r0 + per);
     const int nch = r1 > r0 ? (int)((r1 - r0 + GCH - 1) / GCH) : 0;
