@@ -43,6 +43,12 @@
 
 namespace {
 
+// waves of the forward's workgroup: 4 (one per SIMD) or 8 (two per SIMD, -DMPO_F32_FWD_WAVES=8 through tools/build_variant.py).
+// Measured the same on the same box (1.27 against 1.24-1.30 ms per 8 x 100 000 window, r03): the kernel is not limited by a
+// wave waiting on itself but by the matrix pipe at the clock the chip holds under this load.
+#ifndef MPO_F32_FWD_WAVES
+#define MPO_F32_FWD_WAVES 4
+#endif
 constexpr int FE = 256;                         // embed_dim
 constexpr int FK = 1024;                        // patch feature width
 constexpr int FBM = 128;                        // rows per block
@@ -87,7 +93,10 @@ __global__ void pack_patch_weight_f32_kernel(const float* __restrict__ w, f16x8*
     out[FE * FK / 8 + t] = lo;
 }
 
-__global__ __launch_bounds__(256, 1)
+// NW waves per workgroup (4: one per SIMD, 64 embed columns each; 8: two per SIMD, 32 each -- the same packed weight, the same
+// dropout mask, the same arithmetic per element)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1)
 void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows][1024]
                          const f16x8* __restrict__ wpk,           // packed hi | lo (pack_patch_weight_f32_kernel)
                          const float* __restrict__ bias,          // [256]
@@ -104,13 +113,20 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
     if (wg_r0 >= wg_r1) return;
     const int nblocks = (int)((wg_r1 - wg_r0 + FBM - 1) / FBM);
 
-    // staging: thread (row = tid >> 1, half = tid & 1) carries k = 16 half .. + 15 of its row: four float4
-    const int srow = tid >> 1, shalf = tid & 1;
+    constexpr int NCT = 16 / NW;                                         // 16-column tiles a wave owns
+    constexpr int TPR = NW / 2;                                          // threads per row of the X tile
+    constexpr int NF4 = 8 / TPR;                                         // float4 per thread and step (k = 4 NF4 spart .. + 4 NF4 - 1)
+    constexpr int NCHK = NF4 / 2;                                        // 16-byte image chunks per thread
+    // staging: thread (row = tid / TPR, part = tid % TPR) carries 4 NF4 consecutive k of its row
+    const int srow = tid / TPR, spart = tid % TPR;
     const int sswz = (srow >> 2) & 3;
-    const int soff0 = srow * FROWB + (((2 * shalf) ^ sswz) << 4), soff1 = srow * FROWB + (((2 * shalf + 1) ^ sswz) << 4);
+    int soff[NCHK];
+#pragma unroll
+    for (int c = 0; c < NCHK; ++c) soff[c] = srow * FROWB + (((NCHK * spart + c) ^ sswz) << 4);
+    const int wave4 = wave / (NW / 4), ct0 = NCT * (wave % (NW / 4));   // position in the packed weight's [wave 4][..][ct 4] order
     // fragment reads: row 16 rt + c16, chunk g
     const int foff = c16 * FROWB + ((g ^ ((c16 >> 2) & 3)) << 4);
-    const f16x8* whi = wpk + (size_t)wave * (FSTEPS * 4 * 64) + lane;
+    const f16x8* whi = wpk + (size_t)wave4 * (FSTEPS * 4 * 64) + ct0 * 64 + lane;
     const f16x8* wlo = whi + FE * FK / 8;
     const uint32_t thr8 = (uint32_t)(drop_p * 256.0f + 0.5f);
     const float inv_keep = drop_p > 0.f ? 256.0f / (256.0f - (float)thr8) : 1.0f;
@@ -120,10 +136,10 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
     for (int blk = 0; blk < nblocks; ++blk) {
         const long long rb = wg_r0 + (long long)blk * FBM;
         const long long grow = min(rb + srow, total_rows - 1);           // rows past the end: clamped (finite; never stored)
-        const float* xrow = x + (size_t)grow * FK + 16 * shalf;
-        f32x4 acc[4][8];
+        const float* xrow = x + (size_t)grow * FK + 4 * NF4 * spart;
+        f32x4 acc[NCT][8];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) acc[ct][rt] = zero4;
         // Operand pipeline, three register sets each in static rotation (three steps per trip, no copies): step k multiplies the
@@ -131,29 +147,29 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
         // splits x(k + 1) -- requested in the previous step -- into the other stage AFTER the step's MFMAs are issued (four sets
         // each, three steps ahead, spilled 98 registers).  One step of matrix work (~0.8 us) does not
         // cover an HBM or a loaded-L2 round trip: with one step of lookahead every step began by waiting for its operands.
-        f32x4 xs[3][4];
-        f16x8 wh[3][4], wl[3][4];
-        auto load_x = [&](f32x4 (&dst)[4], int k) {
+        f32x4 xs[3][NF4];
+        f16x8 wh[3][NCT], wl[3][NCT];
+        auto load_x = [&](f32x4 (&dst)[NF4], int k) {
             k = k < FSTEPS ? k : FSTEPS - 1;                              // (past the end: re-reads the last tile, never used)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const f32x4*>(xrow + FBK * k + 4 * j);
+            for (int j = 0; j < NF4; ++j) dst[j] = *reinterpret_cast<const f32x4*>(xrow + FBK * k + 4 * j);
         };
-        auto load_w = [&](f16x8 (&h_)[4], f16x8 (&l_)[4], int k) {
+        auto load_w = [&](f16x8 (&h_)[NCT], f16x8 (&l_)[NCT], int k) {
             k = k < FSTEPS ? k : FSTEPS - 1;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 h_[ct] = whi[(k * 4 + ct) * 64];
                 l_[ct] = wlo[(k * 4 + ct) * 64];
             }
         };
-        auto split_tile = [&](const f32x4 (&src)[4], char* st) {
-            f16x8 h0, l0, h1, l1;
-            split8h(src[0], src[1], 1.0f, h0, l0);
-            split8h(src[2], src[3], 1.0f, h1, l1);
-            *reinterpret_cast<f16x8*>(st + soff0) = h0;
-            *reinterpret_cast<f16x8*>(st + soff1) = h1;
-            *reinterpret_cast<f16x8*>(st + FIMG + soff0) = l0;
-            *reinterpret_cast<f16x8*>(st + FIMG + soff1) = l1;
+        auto split_tile = [&](const f32x4 (&src)[NF4], char* st) {
+#pragma unroll
+            for (int c = 0; c < NCHK; ++c) {
+                f16x8 h0, l0;
+                split8h(src[2 * c], src[2 * c + 1], 1.0f, h0, l0);
+                *reinterpret_cast<f16x8*>(st + soff[c]) = h0;
+                *reinterpret_cast<f16x8*>(st + FIMG + soff[c]) = l0;
+            }
         };
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -162,8 +178,8 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
         }
         split_tile(xs[0], lds);
         // one K-step with the register sets named statically: j = k % 3
-        auto step = [&](int k, const f16x8 (&wh_)[4], const f16x8 (&wl_)[4], f16x8 (&whn)[4], f16x8 (&wln)[4], f32x4 (&xn)[4],
-                        const f32x4 (&xsplit)[4]) {
+        auto step = [&](int k, const f16x8 (&wh_)[NCT], const f16x8 (&wl_)[NCT], f16x8 (&whn)[NCT], f16x8 (&wln)[NCT], f32x4 (&xn)[NF4],
+                        const f32x4 (&xsplit)[NF4]) {
             const char* st = lds + (k & 1) * (2 * FIMG);
             __syncthreads();                                              // the images of x(k) are complete; the other stage is free
             load_x(xn, k + 2);
@@ -179,20 +195,20 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
                 // term-major: the three MFMAs of one accumulator are DEPENDENT (each waits for the previous result); with the
                 // four column tiles in between every MFMA finds its accumulator ready
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct][rt] = mfma_f16(wh_[ct], xh[rt], acc[ct][rt]);
+                for (int ct = 0; ct < NCT; ++ct) acc[ct][rt] = mfma_f16(wh_[ct], xh[rt], acc[ct][rt]);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct][rt] = mfma_f16(wh_[ct], xl[rt], acc[ct][rt]);
+                for (int ct = 0; ct < NCT; ++ct) acc[ct][rt] = mfma_f16(wh_[ct], xl[rt], acc[ct][rt]);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct][rt] = mfma_f16(wl_[ct], xh[rt], acc[ct][rt]);
+                for (int ct = 0; ct < NCT; ++ct) acc[ct][rt] = mfma_f16(wl_[ct], xh[rt], acc[ct][rt]);
             }
             // (the scheduler otherwise sinks every read to its first use: reads first, four fragments ahead of the MFMAs)
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);       // one row tile's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NCT, 0);  // one row tile's MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // the fragments of row tile j + 2
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NCT, 0);
             if (k + 1 < FSTEPS) split_tile(xsplit, lds + ((k + 1) & 1) * (2 * FIMG));       // (vector work behind the queued matrix work)
         };
 #pragma unroll 1
@@ -204,25 +220,28 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
         step(FSTEPS - 2, wh[0], wl[0], wh[2], wl[2], xs[2], xs[1]);
         step(FSTEPS - 1, wh[1], wl[1], wh[0], wl[0], xs[0], xs[2]);
         // epilogue: acc[ct][rt][r] = H^T: embed column 64 wave + 16 ct + 4 g + r of patch row 16 rt + c16
-        f32x4 bv[4];
+        f32x4 bv[NCT];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + 64 * wave + 16 * ct + 4 * g);
+        for (int ct = 0; ct < NCT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + 64 * wave4 + 16 * (ct0 + ct) + 4 * g);
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt) {
             const long long row = rb + 16 * rt + c16;
             uint4 rnd = {0u, 0u, 0u, 0u};
-            if (drop_p > 0.f) rnd = hash4x32(drop_key, (unsigned long long)row * 16ull + (unsigned)(4 * wave + g));
+            if (drop_p > 0.f) rnd = hash4x32(drop_key, (unsigned long long)row * 16ull + (unsigned)(4 * wave4 + g));
             const uint32_t rw[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+            uint32_t rwc[NCT];                                           // words ct0 .. ct0 + NCT - 1 (ct0 is wave-uniform: selects, no indexing)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) rwc[ct] = NCT == 4 ? rw[ct] : (ct0 == 0 ? rw[ct] : rw[(2 + ct) & 3]);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = fmaxf(acc[ct][rt][r] * (1.0f / kWScale) + bv[ct][r], 0.f);
-                    if (drop_p > 0.f) v = (((rw[ct] >> (8 * r)) & 0xFFu) >= thr8) ? v * inv_keep : 0.f;
+                    if (drop_p > 0.f) v = (((rwc[ct] >> (8 * r)) & 0xFFu) >= thr8) ? v * inv_keep : 0.f;
                     o[r] = v;
                 }
-                if (row < wg_r1) *reinterpret_cast<f32x4*>(h + (size_t)row * FE + 64 * wave + 16 * ct + 4 * g) = o;
+                if (row < wg_r1) *reinterpret_cast<f32x4*>(h + (size_t)row * FE + 64 * wave4 + 16 * (ct0 + ct) + 4 * g) = o;
             }
         }
         __syncthreads();                                                  // (the next block's first split writes stage 0)
@@ -399,7 +418,7 @@ int mpo_launch_patch_fc_f32(const float* x, const float* w, const float* bias, f
     long long per = (total_rows + target - 1) / target;
     per = (per + FBM - 1) / FBM * FBM;
     const int grid = (int)((total_rows + per - 1) / per);
-    patch_fc_f32_kernel<<<grid, 256, 0, stream>>>(x, reinterpret_cast<const f16x8*>(ws), bias, h, total_rows, (int)per, drop_p, seed,
+    patch_fc_f32_kernel<MPO_F32_FWD_WAVES><<<grid, 64 * MPO_F32_FWD_WAVES, 0, stream>>>(x, reinterpret_cast<const f16x8*>(ws), bias, h, total_rows, (int)per, drop_p, seed,
                                                    offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
