@@ -362,7 +362,7 @@ def test_cesar_window_loss_matches_oracle(dev, kind):
 
 
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])
-@pytest.mark.parametrize("n_groups", [1, 3, 9, 15, 16])
+@pytest.mark.parametrize("n_groups", [1, 3, 7, 8, 9, 15, 16])
 def test_other_omic_group_counts_and_tiny_bags(dev, kind, n_groups):
     """The number of omic queries is a model argument (len(omic_sizes), models/mcat/mcat.py:32-45), not a constant 6: 1, 3, 9
     and the MFMA-column maximum 16 groups, over a ragged window whose bags straddle every tile boundary (1, 2, 31, 32, 33,
