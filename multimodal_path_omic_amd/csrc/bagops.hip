@@ -872,8 +872,11 @@ void bag_key_grad_kernel(const float* __restrict__ kbag, const int* __restrict__
     const float* w2b = w2 + (size_t)n_q * sg.row_begin;
     const float* kslide = kbag + (size_t)sg.row_begin * E_;
     char* dslide = reinterpret_cast<char*>(dk) + (size_t)sg.row_begin * E_ * (OUT_BF16 ? 2 : 4);
-    auto step_row = [&](int st) { return sg.r0 + kTileRows * (wave + (st >> 1) * WAVES) + HR * (st & 1); };
-    const int n_steps = 2 * sg.n_my;
+    // 16-row steps dealt to the waves one by one (not 32-row tiles: 59 tiles over 8 waves leave five waves idle for a whole
+    // tile in the last round, 118 steps for half of one)
+    const int n_units = sg.r1 > sg.r0 ? (sg.r1 - sg.r0 + HR - 1) / HR : 0;
+    auto step_row = [&](int st) { return sg.r0 + HR * (wave + st * WAVES); };
+    const int n_steps = wave < n_units ? (n_units - wave + WAVES - 1) / WAVES : 0;
     // map columns of a step: lane (m = lane & 15, quarter = lane >> 4) holds queries quarter and quarter + 4
     const int tm = lane & 15, tq = lane >> 4;
     float wn[4];                                             // W1[tq], W1[tq + 4], W2[tq], W2[tq + 4] at row tm of the NEXT step

@@ -73,7 +73,6 @@ void coattn_bwd_f32_kernel(const float* __restrict__ bag, const int* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const WgGeom wg = wg_geom(cu, plan);
     const int b = wg.b, m_rows = wg.m_rows, r0 = wg.r0, r1 = wg.r1;
-    const int n_my = wave < wg.ntiles ? (wg.ntiles - wave + F_WAVES - 1) / F_WAVES : 0;
 
     // the lane's 4 columns of qk (log2 units) and dctx; lse and delta per query (rows n >= n_q: zero operands, A = 0)
     f32x4 qk[NQA], dc[NQA];
@@ -101,8 +100,10 @@ void coattn_bwd_f32_kernel(const float* __restrict__ bag, const int* __restrict_
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     const float* slide = bag + (size_t)wg.row_begin * F_E;
     float* dslide = dbag + (size_t)wg.row_begin * F_E;
-    auto step_row = [&](int st) { return r0 + kTileRows * (wave + (st >> 1) * F_WAVES) + F_HR * (st & 1); };
-    const int n_steps = 2 * n_my;
+    // 16-row steps dealt to the waves one by one (59 tiles over 8 waves idle five waves for a whole tile in the last round)
+    const int n_units = r1 > r0 ? (r1 - r0 + F_HR - 1) / F_HR : 0;
+    auto step_row = [&](int st) { return r0 + F_HR * (wave + st * F_WAVES); };
+    const int n_steps = wave < n_units ? (n_units - wave + F_WAVES - 1) / F_WAVES : 0;
 
     f32x4 hv[F_HR];
     auto fetch_row = [&](int st, int i) {
