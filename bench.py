@@ -155,10 +155,11 @@ def _stored_profile(name, avg_us, applies):
 
 
 def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=None):
-    """Time the model's long-bag cross-attention forward kernel alone over a window of bags against its ALGORITHMIC bytes
+    """Time the model's dominant long-bag forward kernel alone over a window of bags against its ALGORITHMIC bytes
     (DESIGN.md section 3):
-      MCAT, bf16 window (the headline): the fused patch-layer + co-attention pass (row f1): reads the raw patch matrix
-        once, writes H_bag once: M * (1024 + 256) * 2 bytes per slide;
+      MCAT, bf16 window (the headline): the patch-layer pass (rows H2 / f1, patch_fc_fwd_kernel): reads the raw patch matrix
+        once, writes H_bag once: M * (1024 + 256) * 2 bytes per slide; the co-attention itself (K1's forward pass over
+        H_bag, M * 256 * 2 bytes per slide) is timed the same way and reported under "cross_attention";
       MCAT, fp32 window: K1's coattn_fwd_partial over H_bag, M * 256 * 4 bytes per slide;
       NaCAGaT: K2's bag_rowdot_gated over the key bag, fp32 whatever the bag dtype: M * 256 * 4 bytes per slide."""
     import torch
@@ -185,11 +186,11 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=
         h_out = torch.empty(window * patches, E, device=dev, dtype=torch.bfloat16)
 
         def launch(i):
-            L.check(lib.mpo_patch_coattn_fwd_bagpass(L.ptr(xs[i & 1]), L.ptr(wb), L.ptr(bias), L.ptr(cu), window, L.ptr(qk2),
-                                                     L.ptr(h_out), L.ptr(part_ml), L.ptr(part_ctx), n_q, patches, 0.25, 1, 0,
+            L.check(lib.mpo_patch_coattn_fwd_bagpass(L.ptr(xs[i & 1]), L.ptr(wb), L.ptr(bias), L.ptr(cu), window, None,
+                                                     L.ptr(h_out), None, None, n_q, patches, 0.25, 1, 0,
                                                      plan, stream.cuda_stream), "mpo_patch_coattn_fwd_bagpass")
         alg_bytes = window * patches * (1024 + E) * 2
-        name = "patch_coattn_fwd_kernel<1024->256, bf16>"
+        name = "patch_fc_fwd_kernel<1024->256, bf16>"
         tname = "f1_fwd_traffic.json"
         applies = window == 32 and patches == 15000
     else:
@@ -219,6 +220,21 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=
     avg_us = sum(us) / len(us)
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
     traffic, mfma_util, source = _stored_profile(tname, avg_us, applies)
+    if fused:
+        # the cross-attention proper (north_star: "the 15k-patch cross-attention kernel"): K1's forward bag pass over the bf16 H_bag
+        hb = [torch.relu(torch.randn(window * patches, E, device=dev)).to(torch.bfloat16) for _ in range(2)]
+
+        def launch_k1(i):
+            L.check(lib.mpo_coattn_fwd_bagpass(L.ptr(hb[i & 1]), L.bag_dtype_code(hb[0]), L.ptr(cu), window, E, L.ptr(qk2),
+                                               L.ptr(part_ml), L.ptr(part_ctx), None, n_q, patches, plan, stream.cuda_stream),
+                    "mpo_coattn_fwd_bagpass")
+        us1, burst1 = _time_launches(dev, launch_k1, reps, between=between)
+        a1 = sum(us1) / len(us1)
+        b1 = window * patches * E * 2
+        extra["cross_attention"] = {"kernel": "coattn_fwd_partial_kernel<256,bf16>", "bound": "hbm", "algorithmic_bytes_per_launch": b1,
+                                    "avg_launch_us": round(a1, 2), "min_launch_us": round(us1[0], 2),
+                                    "achieved": round(b1 / (a1 * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(b1 / (a1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "launches_timed": reps * burst1}
     return {**extra, "bound": "hbm", "kernel": name,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_util": mfma_util,

@@ -206,9 +206,9 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
     if ((rc = mpo_launch_pack_patch_weight(patch_weight, w_bf16, E, patch_dim, stream))) return rc;
     if ((rc = mpo_linear_fwd(query, in_w, in_b, qs, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_linear_bwd_input(qs, in_w + (size_t)E * E, qk2, R, E, E, kLog2e, 0, stream))) return rc;
-    if ((rc = mpo_launch_patch_coattn_fwd(patches, w_bf16, patch_bias, cu_rows, qk2, h_bag, part_ml, part_ctx, attn_map, n_q,
-                                          drop_p, seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), plan,
-                                          stream))) return rc;
+    if ((rc = mpo_launch_patch_fc_fwd(patches, w_bf16, patch_bias, cu_rows, h_bag, drop_p, seed, offset,
+                                      reinterpret_cast<const unsigned long long*>(rng_epoch), plan, stream))) return rc;
+    if ((rc = mpo_launch_coattn_fwd_partial(h_bag, 0, cu_rows, n_slides, E, qk2, part_ml, part_ctx, attn_map, n_q, plan, stream))) return rc;
     if ((rc = mpo_launch_coattn_combine(part_ml, part_ctx, ctx, lse2, n_slides, n_q, E, plan, stream))) return rc;
     if ((rc = mpo_linear_fwd(ctx, in_w + (size_t)2 * E * E, in_b + 2 * E, attn, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_linear_fwd(attn, out_w, out_b, out, R, E, E, 1.0f, MPO_ACT_NONE, stream))) return rc;
@@ -234,8 +234,8 @@ int mpo_patch_fc_forward(const void* patches, const int32_t* cu_rows, int n_slid
     MPO_CHECK(w_bf16, "patch layer: workspace too small (%zu bytes)", workspace_bytes);
     int rc;
     if ((rc = mpo_launch_pack_patch_weight(patch_weight, w_bf16, embed, patch_dim, stream))) return rc;
-    return mpo_launch_patch_coattn_fwd(patches, w_bf16, patch_bias, cu_rows, nullptr, h_bag, nullptr, nullptr, nullptr, 0, drop_p,
-                                       seed, offset, reinterpret_cast<const unsigned long long*>(rng_epoch), plan, stream);
+    return mpo_launch_patch_fc_fwd(patches, w_bf16, patch_bias, cu_rows, h_bag, drop_p, seed, offset,
+                                   reinterpret_cast<const unsigned long long*>(rng_epoch), plan, stream);
 }
 
 // fp32-stored window: the patch layer on patch_fc_f32.hip
@@ -270,8 +270,9 @@ int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_packed, cons
                                  float drop_p, uint64_t seed, uint64_t offset, const mpo_bag_plan* plan_, mpo_stream_t stream) {
     const BagPlan plan = make_plan(plan_, n_slides, max_rows);
     if (int rc = check_plan(plan, n_slides)) return rc;
-    return mpo_launch_patch_coattn_fwd(patches, w_packed, bias, cu_rows, qk2, h_bag, part_ml, part_ctx, nullptr, n_q, drop_p, seed,
-                                       offset, nullptr, plan, stream);
+    if (int rc = mpo_launch_patch_fc_fwd(patches, w_packed, bias, cu_rows, h_bag, drop_p, seed, offset, nullptr, plan, stream)) return rc;
+    if (qk2 == nullptr) return 0;
+    return mpo_launch_coattn_fwd_partial(h_bag, 0, cu_rows, n_slides, 256, qk2, part_ml, part_ctx, nullptr, n_q, plan, stream);
 }
 int mpo_pack_patch_weight(const float* weight, void* packed, int embed, int patch_dim, mpo_stream_t stream) {
     return mpo_launch_pack_patch_weight(weight, packed, embed, patch_dim, stream);

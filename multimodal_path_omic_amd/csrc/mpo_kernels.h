@@ -138,12 +138,11 @@ inline int mpo_gemm_together(hipStream_t s, const GemmArgs& a, const GemmArgs& b
 // ---- K1/K2 long-bag cross-attention (coattn_fwd.hip / coattn_bwd.hip)
 struct BagPlan;
 extern "C" int mpo_coattn_splits(int n_slides, int max_rows);
-// row f1: patch layer + K1 forward in one pass over the raw patch matrix (patch_coattn_fwd.hip)
+// rows H2 / f1: the patch layer of a bf16 window, 1024 -> 256, one pass over the raw patch matrix (patch_fc_fwd.hip)
 int mpo_launch_pack_patch_weight(const float* w, void* out, int embed, int patch_dim, hipStream_t stream);
-int mpo_launch_patch_coattn_fwd(const void* x, const void* w_bf16, const float* bias, const int* cu, const float* qk2,
-                                void* h_out, float* part_ml, float* part_ctx, float* s_out, int n_q, float drop_p,
-                                unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
-                                const BagPlan& plan, hipStream_t stream);
+int mpo_launch_patch_fc_fwd(const void* x, const void* w_packed, const float* bias, const int* cu, void* h_out, float drop_p,
+                            unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
+                            const BagPlan& plan, hipStream_t stream);
 int mpo_launch_coattn_fwd_partial(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
                                   const float* qk2, float* part_ml, float* part_ctx, float* s_out,
                                   int n_q, const BagPlan& plan, hipStream_t stream);

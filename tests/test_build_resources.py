@@ -45,7 +45,7 @@ def test_no_unexpected_scratch(usage):
 
 def test_headline_kernels_are_register_resident(usage):
     """The kernels the bench line is made of (E=256, bf16 bag) must have no scratch and no spills at all."""
-    hot = ["coattn_fwd_partial_kernelILi256ELb0", "coattn_bwd_kernelILi256ELb0", "coattn_bwd8_kernel", "bag_rowdot_gated_exact_kernelILi256E", "patch_coattn_fwd_kernel", "patch_wgrad_kernel",
+    hot = ["coattn_fwd_partial_kernelILi256ELb0", "coattn_bwd_kernelILi256ELb0", "coattn_bwd8_kernel", "bag_rowdot_gated_exact_kernelILi256E", "patch_fc_fwd_kernel", "patch_wgrad_kernel",
            "bag_colacc_gated_kernelILi256ELb1", "bag_outer_gated_kernelILi256ELb1", "bag_key_grad_kernelILi256ELb1ELi6",
            "coattn_bwd_f32_kernel", "gemm_f32_direct_kernelILi4",
            "gemm_f32_direct_kernelILi8",
@@ -60,7 +60,7 @@ def test_headline_kernels_are_register_resident(usage):
             assert v["scratch_bytes"] == 0 and v["vgpr_spill"] == 0, (h, v)
 
 
-@pytest.mark.parametrize("source", ["coattn_fwd.hip", "coattn_bwd8.hip", "bag_selfattn.hip", "patch_coattn_fwd.hip", "patch_wgrad.hip"])
+@pytest.mark.parametrize("source", ["coattn_fwd.hip", "coattn_bwd8.hip", "bag_selfattn.hip", "patch_fc_fwd.hip", "patch_wgrad.hip"])
 def test_m0_is_only_touched_by_the_direct_to_lds_loads(tmp_path, source):
     """K1 forward, the fused patch-layer kernel (the headline kernel), the patch-layer weight gradient and the
     head-dimension-256 bag self-attention kernels issue their tile loads from inline asm that sets

@@ -87,10 +87,9 @@ for size, dd in (("small", 128), ("medium", 256), ("big", 512)):
     swap(ref, "path_attention_head", AttentionNetGated(n_classes=1, input_dim=dd, hidden_dim=dd))
     after = ref.state_dict()
     assert list(after) == list(before) and all(torch.equal(before[k], after[k]) for k in before)
-    if size != "big":                              # 'big' (one attention head of 512) is refused at construction
-        whole = ours.GeneExprNarrowContextualAttentionGateTransformer(model_size=size)
-        whole.load_state_dict(before, strict=True)
-        assert list(whole.state_dict()) == list(before)
+    whole = ours.GeneExprNarrowContextualAttentionGateTransformer(model_size=size)
+    whole.load_state_dict(before, strict=True)
+    assert list(whole.state_dict()) == list(before)
     print("ok", "ge_nacagat", size, len(before))
 """
 

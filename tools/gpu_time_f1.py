@@ -1,4 +1,4 @@
-"""The fused patch-layer + co-attention bag pass (row f1) timed alone on a 32 x 15000 x 1024 bf16 window (two resident
+"""The patch-layer bag pass (rows H2 / f1; K1=1: followed by K1's forward bag pass) timed alone on a 32 x 15000 x 1024 bf16 window (two resident
 windows alternated); also the rocprofv3 workload of profiles/r02_f1_*.  DROP=<p> sets the dropout rate (default 0.25)."""
 import os
 import sys
@@ -31,8 +31,11 @@ qk2 = torch.randn(window * n_q, E, device=dev) * 0.05
 drop = float(os.environ.get("DROP", "0.25"))
 
 
+with_k1 = os.environ.get("K1", "0") == "1"          # K1=1: the patch-layer pass followed by K1's forward pass (two launches)
+
+
 def launch(i):
-    L.check(lib.mpo_patch_coattn_fwd_bagpass(L.ptr(xs[i & 1]), L.ptr(wb), L.ptr(bias), L.ptr(cu), window, L.ptr(qk2), L.ptr(h_out),
+    L.check(lib.mpo_patch_coattn_fwd_bagpass(L.ptr(xs[i & 1]), L.ptr(wb), L.ptr(bias), L.ptr(cu), window, L.ptr(qk2) if with_k1 else None, L.ptr(h_out),
                                              L.ptr(part_ml), L.ptr(part_ctx), n_q, patches, drop, 1, 0, plan, stream.cuda_stream), "bagpass")
 
 
@@ -47,5 +50,5 @@ for i, (s, e) in enumerate(evs):
     e.record()
 torch.cuda.synchronize()
 us = sorted(s.elapsed_time(e) * 250 for s, e in evs)
-print(f"drop={drop}: min {us[0]:.1f} us, median {us[len(us) // 2]:.1f} us "
+print(f"drop={drop} k1={int(with_k1)}: min {us[0]:.1f} us, median {us[len(us) // 2]:.1f} us "
       f"({window * patches * 1280 * 2 / us[len(us) // 2] / 1e6:.2f} TB/s algorithmic)")
