@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BASE_SEED = 1234               # synthetic inputs from seed 1234 + config index / rank
-SETTLE_STEPS = 40            # untimed replays after graph capture and before the W warmup steps (setup; see run_config)
+SETTLE_STEPS = 40            # default of --settle: untimed replays after graph capture and before the W warmup steps (setup; see run_config)
 
 
 def parse(argv=None):
@@ -46,6 +46,9 @@ def parse(argv=None):
                     help="BASELINE cfg 4: bag lengths drawn uniformly from [2000, 30000] (fixed multiset, length-aware "
                          "assignment of each window's slides to ranks) instead of --patches for every slide")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle", type=int, default=SETTLE_STEPS,
+                    help="untimed replays of the captured step BEFORE the --warmup steps (clock / residency settling; reported as "
+                         "config.setup_replays_before_warmup; 0 = the bare W-warmup / K-timed contract)")
     ap.add_argument("--no-extras", action="store_true", help="headline configuration only")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured HIP graph")
     return ap.parse_args(argv)
@@ -288,10 +291,7 @@ def _all_ranks_ok(ok: bool, dev, world) -> bool:
     return bool(t.item())
 
 
-def ge_cpu_baseline_leg(patches=15000):
-    """Row f3's CPU baseline: the oracle's gene-expression model (kind 'port') on ONE bag of the benchmarked length -- forward,
-    cross-entropy, backward, fp32, all host threads.  One slide is the bounded sample: the reference algorithm keeps the
-    8-head M x M probabilities of both encoder layers for the backward (~45 GB at M = 15 000) and takes tens of seconds."""
+def _ge_cpu_leg_inprocess(patches=15000):
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import cases as C
@@ -308,6 +308,30 @@ def ge_cpu_baseline_leg(patches=15000):
     dt = time.perf_counter() - t0
     return {"value": round(1.0 / dt, 4), "unit": "slides/s", "cores": threads, "kind": "port",
             "sample": f"1 slide of {patches}x1024 fp32, GE-NaCAGaT medium, fwd+CE+bwd ({dt:.1f} s)"}
+
+
+def ge_cpu_baseline_leg(patches=15000, timeout_s=180, need_gib=64):
+    """Row f3's CPU baseline: the oracle's gene-expression model (kind 'port') on ONE bag of the benchmarked length -- forward,
+    cross-entropy, backward, fp32, all host threads.  One slide is the bounded sample: the reference algorithm keeps the
+    8-head M x M probabilities of both encoder layers for the backward (~45 GB at M = 15 000) and takes tens of seconds.
+    Because of that footprint it runs in a CHILD process, after a check of the host's free memory and under a time limit:
+    a kill of the child (out of memory, limit) costs this leg, never the bench line."""
+    import subprocess
+    try:
+        with open("/proc/meminfo") as f:
+            avail = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable:")) / 2 ** 20
+    except Exception:
+        avail = None
+    if avail is not None and avail < need_gib:
+        return {"error": f"skipped: {avail:.0f} GiB of host memory available, the oracle needs ~45 GiB (limit {need_gib})"}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--_ge_cpu_leg", str(patches)], capture_output=True, text=True,
+                           timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"child process exceeded {timeout_s} s"}
+    if r.returncode != 0:
+        return {"error": f"child process exit code {r.returncode}: {r.stderr[-160:]}"}
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
@@ -374,7 +398,7 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
     # state or for the first touch of the second resident window (the timed region of the driver's K = 20 is 22 ms long: one
     # 5 ms hiccup is a quarter of it -- seen once in round 3, 1.37 ms per step with every kernel at its usual time under
     # rocprofv3 minutes later).  Then the contract: W untimed warmup steps, exactly K timed ones.
-    for i in range(SETTLE_STEPS):
+    for i in range(a.settle):
         step(i)
     torch.cuda.synchronize(dev)
     for i in range(warmup):
@@ -406,7 +430,7 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
                        "global_slides_per_step": world * a.window,
                        "patches_per_slide": "uniform[2000,30000] (fixed multiset)" if a.ragged else a.patches,
                        "parallelism": f"dp{world}", "resident_windows": a.n_windows, "launch": graph_note,
-                       "setup_replays_before_warmup": SETTLE_STEPS},
+                       "setup_replays_before_warmup": a.settle},
         }
     if rank == 0 and with_roofline:
         # the roofline kernel is timed inside the workload it belongs to: a replay of the captured step before every
@@ -504,6 +528,9 @@ def extras(a, dev, rank, world):
 
 def main():
     argv = sys.argv[1:]
+    if argv[:1] == ["--_ge_cpu_leg"]:                             # the child of ge_cpu_baseline_leg(): CPU only, no GPU touched
+        print(json.dumps(_ge_cpu_leg_inprocess(int(argv[1]))), flush=True)
+        return
     a = parse(argv)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, argv))

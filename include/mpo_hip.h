@@ -8,8 +8,13 @@
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
  *     (PyTorch allocates inputs, outputs, saved tensors and workspaces; the library allocates nothing
  *     persistent and keeps no pointer after returning);
- *   - asynchronous on the hipStream_t passed last; re-entrant; no global mutable state except the
- *     thread-local last-error string;
+ *   - asynchronous on the hipStream_t passed last; the compute entries are re-entrant and keep no state of their
+ *     own.  Process-global state of the library: the thread-local last-error string, and the kernel SELECTORS
+ *     mpo_set_* below (diagnostic switches that pick between two kernels computing the same values; they exist so
+ *     that the tests can hold each special kernel against the general one).  A selector is read once per call, on
+ *     the calling thread, before any launch: flipping one while another thread is inside a compute entry changes
+ *     which kernel that call uses, never its result beyond the tolerance the two kernels are tested to.  Production
+ *     code leaves them at their defaults;
  *   - returns 0 on success, non-zero on error (never throws); mpo_last_error() describes it;
  *   - row-major fp32 unless a dtype argument says otherwise; "bag" tensors may be fp32 or bf16
  *     (MPO_F32 / MPO_BF16): bf16 is a STORAGE format, accumulation is always fp32;
@@ -106,17 +111,21 @@ int mpo_patch_fc_forward(const void* patches, const int32_t* cu_rows, int n_slid
                          const float* patch_weight, const float* patch_bias, int embed, float drop_p, uint64_t seed,
                          uint64_t offset, const uint64_t* rng_epoch, void* h_bag, const mpo_bag_plan* plan /* nullable */,
                          void* workspace, size_t workspace_bytes, mpo_stream_t stream);
-/* The patch layer of an fp32-stored window (models/mcat/mcat.py:24-29,87 with fp32 patch features; ABI v11), 1024 -> 256:
- *   forward   H_bag = Dropout(ReLU(X W^T + b)) in fp32 storage; products as three bf16 MFMA terms of hi / lo operand splits with fp32
+/* The patch layer of an fp32-stored window (models/mcat/mcat.py:24-29,87 with fp32 patch features; ABI v11, x_scale: v13), 1024 -> 256:
+ *   forward   H_bag = Dropout(ReLU(X W^T + b)) in fp32 storage; products as three fp16 MFMA terms of hi / lo operand splits with fp32
  *             accumulation (csrc/patch_fc_f32.hip).  Dropout: counter hash, 8 bits per element (realised p = round(256 p) / 256);
- *             the mask lives in H_bag as zeros.
+ *             the mask lives in H_bag as zeros.  x_scale: a power of two applied to X before its split and taken off the
+ *             accumulator (exact); pass 2^(15 - e) for max |X| = m 2^e, m in [0.5, 1) (ops.patch_fc_f32 derives and caches it
+ *             per tensor) so that the features use fp16's range; 1.0 = unscaled (|x| in ~[1e-3, 1.3e5] then).  W_H is scaled
+ *             by its own maximum inside the call.  Non-finite features stay non-finite in their rows of H_bag.
  *   backward  d_weight = g^T X, d_bias = colsum(g) with g = d_h_bag (.) [H_bag > 0] * gate; gate = 1 / (1 - realised p)
  *             (1 without dropout); h_bag NULL: g = d_h_bag.  X needs no gradient (it is data).
  * workspace: caller-owned, mpo_patch_fc_f32_workspace_bytes(backward) bytes. */
 size_t mpo_patch_fc_f32_workspace_bytes(int backward);
 int mpo_patch_fc_f32_forward(const float* patches, int64_t total_rows, int patch_dim, const float* patch_weight,
                              const float* patch_bias, int embed, float drop_p, uint64_t seed, uint64_t offset,
-                             const uint64_t* rng_epoch, float* h_bag, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+                             const uint64_t* rng_epoch, float x_scale, float* h_bag, void* workspace, size_t workspace_bytes,
+                             mpo_stream_t stream);
 int mpo_patch_fc_f32_backward(const float* d_h_bag, const float* h_bag /* nullable */, const float* patches, int64_t total_rows,
                               int embed, int patch_dim, float gate, float* d_weight, float* d_bias, void* workspace,
                               size_t workspace_bytes, mpo_stream_t stream);

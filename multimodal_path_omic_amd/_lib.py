@@ -52,7 +52,7 @@ _SIGNATURES = {
     "mpo_pack_patch_weight": (c_int, [_P, _P, c_int, c_int, _P]),
     "mpo_patch_fc_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mpo_patch_fc_f32_workspace_bytes": (c_size_t, [c_int]),
-    "mpo_patch_fc_f32_forward": (c_int, [_P, ctypes.c_int64, c_int, _P, _P, c_int, c_float, c_uint64, c_uint64, _P, _P, _P, c_size_t, _P]),
+    "mpo_patch_fc_f32_forward": (c_int, [_P, ctypes.c_int64, c_int, _P, _P, c_int, c_float, c_uint64, c_uint64, _P, c_float, _P, _P, c_size_t, _P]),
     "mpo_patch_fc_f32_backward": (c_int, [_P, _P, _P, ctypes.c_int64, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "mpo_patch_fc_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, c_uint64, c_uint64, _P, _P, _P,
                                      _P, c_size_t, _P]),

@@ -83,7 +83,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 12; }
+int mpo_abi_version(void) { return 13; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -244,14 +244,15 @@ size_t mpo_patch_fc_f32_workspace_bytes(int backward) {
 }
 int mpo_patch_fc_f32_forward(const float* patches, int64_t total_rows, int patch_dim, const float* patch_weight,
                              const float* patch_bias, int embed, float drop_p, uint64_t seed, uint64_t offset,
-                             const uint64_t* rng_epoch, float* h_bag, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+                             const uint64_t* rng_epoch, float x_scale, float* h_bag, void* workspace, size_t workspace_bytes,
+                             mpo_stream_t stream) {
     MPO_CHECK(patches && patch_weight && patch_bias && h_bag, "fp32 patch layer: null operand");
     MPO_CHECK(total_rows >= 1, "fp32 patch layer: total_rows %lld", (long long)total_rows);
     Arena ws(workspace, workspace_bytes);
     float* wpk = ws.floats(mpo_patch_fc_f32_workspace_floats());
     MPO_CHECK(wpk, "fp32 patch layer: workspace too small (%zu bytes)", workspace_bytes);
     return mpo_launch_patch_fc_f32(patches, patch_weight, patch_bias, h_bag, total_rows, embed, patch_dim, drop_p, seed, offset,
-                                   reinterpret_cast<const unsigned long long*>(rng_epoch), wpk, stream);
+                                   reinterpret_cast<const unsigned long long*>(rng_epoch), x_scale, wpk, stream);
 }
 int mpo_patch_fc_f32_backward(const float* d_h_bag, const float* h_bag, const float* patches, int64_t total_rows, int embed,
                               int patch_dim, float gate, float* d_weight, float* d_bias, void* workspace, size_t workspace_bytes,

@@ -173,7 +173,7 @@ size_t mpo_patch_fc_f32_workspace_floats();
 size_t mpo_patch_wgrad_f32_workspace_floats();
 int mpo_launch_patch_fc_f32(const float* x, const float* w, const float* bias, float* h, long long total_rows, int embed,
                             int patch_dim, float drop_p, unsigned long long seed, unsigned long long offset,
-                            const unsigned long long* epoch, float* ws, hipStream_t stream);
+                            const unsigned long long* epoch, float x_scale, float* ws, hipStream_t stream);
 int mpo_launch_patch_wgrad_f32(const float* dh, const float* hbag, const float* x, long long total_rows, int embed, int patch_dim,
                                float gate, float* d_weight, float* d_bias, float* ws, hipStream_t stream);
 // K2's patch-side gradient with the product back through the key projection inside the pass (k2_patchgrad.hip)

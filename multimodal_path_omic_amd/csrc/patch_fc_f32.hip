@@ -62,24 +62,51 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
     pack_hi_lo(v, hi, lo);
 }
 // fp16 hi / lo split of eight floats, round-to-nearest both (hi + lo carries 22 significand bits, the dropped lo * lo term
-// is 2^-22 of the product).  hi is clamped to the fp16 range first, so nothing overflows to infinity (lo = x - hi is exact in
-// fp32 and saturates the same way: |x| up to 1.3e5 is carried, beyond that the feature is effectively clipped).
+// is 2^-22 of the product).  Range: both operands arrive scaled by a power of two that puts their largest magnitude at
+// 2^14 .. 2^15 (W_H: from its own maximum, found on the device per call; X: x_scale, which the caller derives from the window's
+// maximum -- ops.patch_fc_f32 caches it per tensor), so finite data never reach the fp16 limit and small features keep
+// their bits (unscaled, features of ~1e-4 sat in fp16 subnormals: ~3e-4 relative).  The clamp only matters for a caller
+// that passes no scale (x_scale = 1: |x| up to 1.3e5 is carried by hi + lo, beyond that clipped).  NaN and infinities are
+// NOT clamped away: v - v is 0 for finite v and NaN otherwise, so a non-finite feature makes its row of H_bag non-finite,
+// as it does in the reference's fp32 GEMM (v_med3 alone returns the bound for a NaN).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split8h(const f32x4& a, const f32x4& b, float scale, f16x8& hi, f16x8& lo) {
     const float v[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale, b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(v[j], -65504.0f, 65504.0f);
+        const _Float16 h = (_Float16)(__builtin_amdgcn_fmed3f(v[j], -65504.0f, 65504.0f) + (v[j] - v[j]));
         hi[j] = h;
         lo[j] = (_Float16)__builtin_amdgcn_fmed3f(v[j] - (float)h, -65504.0f, 65504.0f);
     }
 }
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-constexpr float kWScale = 1024.0f;              // power of two on W_H before its fp16 split; 1 / kWScale on the accumulator
+// The power of two that puts max |v| into [2^14, 2^15) (1 for an all-zero or non-finite maximum).
+__device__ __forceinline__ float range_scale(float vmax) {
+    if (!(vmax > 0.f) || !(vmax < INFINITY)) return 1.0f;
+    int e;
+    (void)frexpf(vmax, &e);                     // vmax = m 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, min(max(15 - e, -100), 100));
+}
+// scale of W_H for this call -> *scale_out (one workgroup of 1024 threads over the 256 x 1024 weight)
+__global__ void weight_range_kernel(const float* __restrict__ w, float* __restrict__ scale_out) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < 256 * 1024 / 4; i += 1024) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(w)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+        *scale_out = range_scale(m);
+    }
+}
 
-// W_H [256][1024] fp32 (x kWScale) -> hi / lo fp16 in fragment order: block (((term * 4 + wave) * 32 + step) * 4 + ct) of 1 KiB holds, for lane
+// W_H [256][1024] fp32 (x *w_scale, weight_range_kernel) -> hi / lo fp16 in fragment order: block (((term * 4 + wave) * 32 + step) * 4 + ct) of 1 KiB holds, for lane
 // (i = lane & 15, g = lane >> 4), W_H[64 wave + 16 ct + i][32 step + 8 g .. + 7]
-__global__ void pack_patch_weight_f32_kernel(const float* __restrict__ w, f16x8* __restrict__ out) {
+__global__ void pack_patch_weight_f32_kernel(const float* __restrict__ w, f16x8* __restrict__ out, const float* __restrict__ w_scale) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;          // one fragment per thread: 256 * 1024 / 8
     if (t >= FE * FK / 8) return;
     const int lane = t & 63, blk = t >> 6;
@@ -88,7 +115,7 @@ __global__ void pack_patch_weight_f32_kernel(const float* __restrict__ w, f16x8*
     const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)row * FK + k0);
     const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)row * FK + k0 + 4);
     f16x8 hi, lo;
-    split8h(a, b, kWScale, hi, lo);
+    split8h(a, b, *w_scale, hi, lo);
     out[t] = hi;
     out[FE * FK / 8 + t] = lo;
 }
@@ -102,7 +129,8 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
                          const float* __restrict__ bias,          // [256]
                          float* __restrict__ h,                   // [total_rows][256]
                          long long total_rows, int rows_per_wg, float drop_p, unsigned long long seed,
-                         unsigned long long offset_, const unsigned long long* __restrict__ epoch) {
+                         unsigned long long offset_, const unsigned long long* __restrict__ epoch,
+                         float x_scale, const float* __restrict__ w_scale) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * FIMG];         // [stage][hi | lo]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,6 +160,7 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
     const float inv_keep = drop_p > 0.f ? 256.0f / (256.0f - (float)thr8) : 1.0f;
     const uint32_t drop_key = hash_stream_key(seed, epoch_offset(offset_, epoch));
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float unscale = 1.0f / (x_scale * *w_scale);            // (powers of two: exact)
 
     for (int blk = 0; blk < nblocks; ++blk) {
         const long long rb = wg_r0 + (long long)blk * FBM;
@@ -166,7 +195,7 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
 #pragma unroll
             for (int c = 0; c < NCHK; ++c) {
                 f16x8 h0, l0;
-                split8h(src[2 * c], src[2 * c + 1], 1.0f, h0, l0);
+                split8h(src[2 * c], src[2 * c + 1], x_scale, h0, l0);
                 *reinterpret_cast<f16x8*>(st + soff[c]) = h0;
                 *reinterpret_cast<f16x8*>(st + FIMG + soff[c]) = l0;
             }
@@ -237,7 +266,7 @@ void patch_fc_f32_kernel(const float* __restrict__ x,             // [total_rows
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = fmaxf(acc[ct][rt][r] * (1.0f / kWScale) + bv[ct][r], 0.f);
+                    float v = __builtin_elementwise_maximum(acc[ct][rt][r] * unscale + bv[ct][r], 0.f);      // (v_maximum3_f32: a NaN stays a NaN, as in torch.relu)
                     if (drop_p > 0.f) v = (((rwc[ct] >> (8 * r)) & 0xFFu) >= thr8) ? v * inv_keep : 0.f;
                     o[r] = v;
                 }
@@ -403,23 +432,30 @@ __global__ void patch_wgrad_f32_reduce_kernel(const float* __restrict__ part, co
 
 }  // namespace
 
-size_t mpo_patch_fc_f32_workspace_floats() { return (size_t)FE * FK; }            // packed hi | lo bf16 weight = 1 MiB
+size_t mpo_patch_fc_f32_workspace_floats() { return (size_t)FE * FK + 64; }       // packed hi | lo fp16 weight = 1 MiB, then its scale
 size_t mpo_patch_wgrad_f32_workspace_floats() { return (size_t)GRANGES * FE * FK + (size_t)GRANGES * FE; }
 
 int mpo_launch_patch_fc_f32(const float* x, const float* w, const float* bias, float* h, long long total_rows, int embed,
                             int patch_dim, float drop_p, unsigned long long seed, unsigned long long offset,
-                            const unsigned long long* epoch, float* ws, hipStream_t stream) {
+                            const unsigned long long* epoch, float x_scale, float* ws, hipStream_t stream) {
     MPO_CHECK(embed == FE && patch_dim == FK, "fp32 patch layer kernel: built for %d -> %d (got %d -> %d)", FK, FE, patch_dim, embed);
     MPO_CHECK(drop_p >= 0.f && drop_p < 1.f, "patch-layer dropout p must be in [0,1) (got %f)", (double)drop_p);
+    {
+        int e = 0;
+        MPO_CHECK(x_scale > 0.f && x_scale < INFINITY && frexpf(x_scale, &e) == 0.5f, "fp32 patch layer: x_scale must be a power of two (got %g)", (double)x_scale);
+    }
     if (total_rows <= 0) return 0;
-    pack_patch_weight_f32_kernel<<<FE * FK / 8 / 256, 256, 0, stream>>>(w, reinterpret_cast<f16x8*>(ws));
+    float* w_scale = ws + (size_t)FE * FK;
+    weight_range_kernel<<<1, 1024, 0, stream>>>(w, w_scale);
+    MPO_LAUNCH_CHECK();
+    pack_patch_weight_f32_kernel<<<FE * FK / 8 / 256, 256, 0, stream>>>(w, reinterpret_cast<f16x8*>(ws), w_scale);
     MPO_LAUNCH_CHECK();
     const int target = 256;
     long long per = (total_rows + target - 1) / target;
     per = (per + FBM - 1) / FBM * FBM;
     const int grid = (int)((total_rows + per - 1) / per);
     patch_fc_f32_kernel<MPO_F32_FWD_WAVES><<<grid, 64 * MPO_F32_FWD_WAVES, 0, stream>>>(x, reinterpret_cast<const f16x8*>(ws), bias, h, total_rows, (int)per, drop_p, seed,
-                                                   offset, epoch);
+                                                   offset, epoch, x_scale, w_scale);
     MPO_LAUNCH_CHECK();
     return 0;
 }

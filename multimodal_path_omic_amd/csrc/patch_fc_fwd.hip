@@ -279,7 +279,7 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
             const f32x2 hi = f32x2{acc[dt][PT][2], acc[dt][PT][3]} * f32x2{inv_keep, inv_keep} + f32x2{bk[dt][2], bk[dt][3]};
             float e[4] = {lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = (((rw[dt] >> (8 * r)) & 0xFFu) >= thr8) ? fmaxf(e[r], 0.f) : 0.f;
+            for (int r = 0; r < 4; ++r) e[r] = (((rw[dt] >> (8 * r)) & 0xFFu) >= thr8) ? __builtin_elementwise_maximum(e[r], 0.f) : 0.f;      // (v_maximum3_f32: a NaN stays a NaN, as in torch.relu)
             o[dt >> 1][2 * (dt & 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e[0], e[1]}, bf16x2));
             o[dt >> 1][2 * (dt & 1) + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e[2], e[3]}, bf16x2));
         }

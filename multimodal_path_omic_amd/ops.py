@@ -7,6 +7,7 @@ tensors, workspaces) are torch allocations; the library keeps nothing.
 from __future__ import annotations
 
 import ctypes
+import math
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -430,7 +431,8 @@ class PatchFcF32Fn(torch.autograd.Function):
         seed, off = _reserve(h.numel() // 16 + 2) if drop_p > 0 else (0, 0)
         ws = _workspace(lib.mpo_patch_fc_f32_workspace_bytes(0), x.device)
         L.check(lib.mpo_patch_fc_f32_forward(L.ptr(x), x.shape[0], x.shape[1], L.ptr(weight), L.ptr(bias), weight.shape[0],
-                                             float(drop_p), seed, off, _epoch(), L.ptr(h), L.ptr(ws), ws.numel(), L.stream_of(x)),
+                                             float(drop_p), seed, off, _epoch(), feature_scale(x), L.ptr(h), L.ptr(ws), ws.numel(),
+                                             L.stream_of(x)),
                 "mpo_patch_fc_f32_forward")
         ctx.save_for_backward(x, h)
         ctx.param_refs = (weight, bias)
@@ -447,6 +449,26 @@ class PatchFcF32Fn(torch.autograd.Function):
         L.check(lib.mpo_patch_fc_f32_backward(L.ptr(dh), L.ptr(h), L.ptr(x), x.shape[0], h.shape[1], x.shape[1], ctx.gate, L.ptr(dw),
                                               L.ptr(db), L.ptr(ws), ws.numel(), L.stream_of(x)), "mpo_patch_fc_f32_backward")
         return None, dw, db, None
+
+
+def feature_scale(x) -> float:
+    """The power of two that puts max |x| of an fp32 patch matrix into [2^14, 2^15): the fp16 operand splits of
+    mpo_patch_fc_f32_forward then use fp16's range whatever the features' own scale (1e-4 or 1e4).  One reduction over the
+    window and one host read, cached on the tensor (a resident window is scanned once; call it -- or one eager forward --
+    before capturing a graph)."""
+    s = getattr(x, "_mpo_feature_scale", None)
+    if s is None:
+        if x.numel() == 0:
+            return 1.0
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("feature_scale(x) needs one host read: call ops.feature_scale(window.data) before capturing the graph")
+        m = float(x.detach().abs().amax())
+        s = math.ldexp(1.0, max(-100, min(100, 15 - math.frexp(m)[1]))) if (m > 0.0 and math.isfinite(m)) else 1.0
+        try:
+            x._mpo_feature_scale = s
+        except AttributeError:
+            pass
+    return s
 
 
 def patch_fc_f32_supported(x, weight) -> bool:

@@ -217,7 +217,7 @@ def test_full_size_bf16_training_window_equals_per_slide(dev, kind):
         # other bf16 neighbour (measured, tools/gpu_diag_window_vs_slide.py); when one of the few dominant elements is among
         # them a row of dW_H moves by up to one bf16 ulp of it, 2^-8 = 3.9e-3 (seen: 4.7e-4 with the r02 two-pass K2 gradient,
         # 1.7e-3 with the one-pass kernel -- other elements flipped, same count).  Everything else is fp32 all the way.
-        bar = 5e-3 if k.startswith("H.") else 5e-4
+        bar = 4e-3 if k.startswith("H.") else 5e-4                # (one bf16 ulp of a dominant element, 2^-8, is the ceiling of that mechanism)
         assert float((grads_w[k] - p.grad).abs().max()) / scale < bar, k
 
 
