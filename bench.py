@@ -46,6 +46,15 @@ def parse(argv=None):
                     help="BASELINE cfg 4: bag lengths drawn uniformly from [2000, 30000] (fixed multiset, length-aware "
                          "assignment of each window's slides to ranks) instead of --patches for every slide")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --window is the GLOBAL accumulation window (the reference's grad_acc_step = 32, "
+                         "models/mcat/main.py:69-74), each of the N ranks holds window / N slides of it, so the optimiser sees "
+                         "the same window -- the same trajectory -- at every N.  Default (weak): --window slides PER RANK, the "
+                         "optimiser's window grows with N.")
+    ap.add_argument("--wgrad-workgroups", type=int, default=None,
+                    help="workgroups of the patch layer's weight-gradient kernel (default: 224 of the 256 CUs at N > 1 -- the "
+                         "gradient all-reduce runs beside it and needs CUs of its own --, one per CU at N = 1)")
+    ap.add_argument("--plan-workgroups", type=int, default=None, help="upper bound on the workgroups of the bag passes' work plan (A/B knob)")
     ap.add_argument("--settle", type=int, default=SETTLE_STEPS,
                     help="untimed replays of the captured step BEFORE the --warmup steps (clock / residency settling; reported as "
                          "config.setup_replays_before_warmup; 0 = the bare W-warmup / K-timed contract)")
@@ -423,7 +432,7 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
         out = {
             "metric": "slides/sec (fwd+bwd) at 15k-patch bags", "value": round(slides / dt, 2), "unit": "slides/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if getattr(a, "strong", False) else "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{a.model.upper()} medium whole model fwd+bwd+Adam, "
                                    f"{'2k-30k' if a.ragged else a.patches}x1024 {a.dtype} patch bag "
                                    f"+ 6x256 omic tokens per slide, ces loss", "slides_per_rank_per_step": a.window,
@@ -499,7 +508,8 @@ def ge_extra(dev, patches=15000, steps=5):
 def extras(a, dev, rank, world):
     """The other BASELINE configs as `extra` entries of the same line: cfg 4 (ragged windows; at every N, it is the
     data-parallel config), and at N = 1 also cfg 3 (NaCAGaT) and cfg 5 (100k-patch fp32 bags, window 8)."""
-    plan = [("cfg4_ragged_2k_30k", dict(model=a.model, ragged=True, patches=15000, dtype="bf16", window=32, n_windows=2), False)]
+    plan = [("cfg4_ragged_2k_30k", dict(model=a.model, ragged=True, patches=15000, dtype="bf16", n_windows=2,
+                                        window=a.window if getattr(a, "strong", False) else 32), False)]
     if world == 1:
         plan += [("cfg3_nacagat_15k", dict(model="nacagat", ragged=False, patches=15000, dtype="bf16", window=32, n_windows=2), True),
                  ("cfg5_mcat_100k_fp32", dict(model="mcat", ragged=False, patches=100000, dtype="f32", window=8, n_windows=2), True)]
@@ -550,6 +560,14 @@ def main():
     dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
 
+    from multimodal_path_omic_amd import ops as _ops
+    _ops.wgrad_workgroups = a.wgrad_workgroups if a.wgrad_workgroups is not None else (224 if world > 1 else None)
+    _ops.plan_workgroups = a.plan_workgroups
+    if a.strong:
+        if a.window % world:
+            sys.exit(f"--strong: the global window of {a.window} slides does not divide over {world} ranks")
+        a.global_window = a.window
+        a.window //= world                                        # per rank; the loss scale 1 / window x the mean over ranks = 1 / global window
     out = run_config(a, dev, rank, world, a.steps, a.warmup)
     if not a.no_extras and not a.ragged and a.model == "mcat" and a.patches == 15000 and a.dtype == "bf16":
         ex = extras(a, dev, rank, world)

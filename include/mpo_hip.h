@@ -176,10 +176,12 @@ int mpo_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, mpo_
  * g^T X over the whole window, g [rows, embed] bf16 = gradient w.r.t. the layer's pre-activation (what
  * mpo_coattn_mcat_backward with bag_relu_gate / mpo_nacagat_patch_grad / mpo_patch_epilogue_backward emit), X the raw bf16
  * patch matrix.  Hand-written split-row kernel (one workgroup per CU, fp32 partials in the workspace + a reduction
- * launch).  Built for embed 256 and patch_dim a multiple of 256 (256 ... 2048). */
+ * launch).  Built for embed 256 and patch_dim a multiple of 256 (256 ... 2048).
+ * workgroups (ABI v13): 0 = one per CU (256); fewer -- a multiple of 8 * patch_dim / 256, e.g. 224 at patch_dim 1024 -- leave
+ * CUs free for a kernel of ANOTHER stream: the gradient all-reduce that a data-parallel step runs beside this product. */
 size_t mpo_patch_weight_grad_workspace_bytes(int embed, int patch_dim);
 int mpo_patch_weight_grad(const void* g_bf16, const void* patches_bf16, int64_t total_rows, int embed, int patch_dim,
-                          float* d_weight, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
+                          float* d_weight, int workgroups, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ---- optimiser step of the reference's default `adam` (models/mcat/main.py:284-300: torch.optim.Adam(lr, weight_decay))
  * over ONE flat parameter / gradient / moment buffer: g' = g + wd p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;

@@ -60,7 +60,7 @@ _SIGNATURES = {
                                          _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
     "mpo_colsum_bf16": (c_int, [_P, _P, ctypes.c_int64, c_int, _P]),
     "mpo_patch_weight_grad_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "mpo_patch_weight_grad": (c_int, [_P, _P, ctypes.c_int64, c_int, c_int, _P, _P, c_size_t, _P]),
+    "mpo_patch_weight_grad": (c_int, [_P, _P, ctypes.c_int64, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "mpo_adam_step_flat": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     "mpo_patch_epilogue_forward": (c_int, [_P, _P, ctypes.c_int64, c_int, c_float, c_uint64, c_uint64, _P, _P]),
     "mpo_patch_epilogue_backward_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int]),

@@ -696,13 +696,13 @@ size_t mpo_patch_weight_grad_workspace_bytes(int embed, int patch_dim) {
     return mpo_patch_wgrad_partial_floats(embed, patch_dim) * sizeof(float) + 256;
 }
 int mpo_patch_weight_grad(const void* g_bf16, const void* patches_bf16, int64_t total_rows, int embed, int patch_dim,
-                          float* d_weight, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
+                          float* d_weight, int workgroups, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     MPO_CHECK(g_bf16 && patches_bf16 && d_weight, "patch weight gradient: null argument");
     MPO_CHECK(total_rows >= 1 && total_rows < (int64_t)1 << 31, "patch weight gradient: %lld rows", (long long)total_rows);
     Arena ws(workspace, workspace_bytes);
     float* part = ws.floats(mpo_patch_wgrad_partial_floats(embed, patch_dim));
     MPO_CHECK(part, "patch weight gradient: workspace too small (%zu bytes)", workspace_bytes);
-    return mpo_launch_patch_wgrad(g_bf16, patches_bf16, (int)total_rows, embed, patch_dim, part, d_weight,
+    return mpo_launch_patch_wgrad(g_bf16, patches_bf16, (int)total_rows, embed, patch_dim, part, d_weight, workgroups,
                                   static_cast<hipStream_t>(stream));
 }
 

@@ -184,7 +184,7 @@ int mpo_gemm_fast_path(int enabled);   // gemm_f32.hip: returns the previous set
 // dW_H = g^T X of the patch layer, hand-written (patch_wgrad.hip): part = mpo_patch_wgrad_partial_floats() floats
 size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim);
 int mpo_launch_patch_wgrad(const void* g_bf16, const void* x_bf16, int total_rows, int embed, int patch_dim, float* part,
-                           float* d_weight, hipStream_t stream);
+                           float* d_weight, int workgroups, hipStream_t stream);
 // what follows a split-M bag pass, one launch: up to two per-slide reductions of [parts][n_q*E] partials, the column
 // sums over all partials of a [parts][cs_cols] array, zero-fills of up to two regions (coattn_bwd.hip: bag_finish_kernel)
 struct BagFinish {

@@ -194,14 +194,19 @@ size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim) {
 }
 
 int mpo_launch_patch_wgrad(const void* g, const void* x, int total_rows, int embed, int patch_dim, float* part, float* d_weight,
-                           hipStream_t stream) {
+                           int workgroups, hipStream_t stream) {
     MPO_CHECK(embed == WG_E && patch_dim >= WG_CB && patch_dim % WG_CB == 0 && (256 % (patch_dim / WG_CB)) == 0,
               "patch weight gradient: built for embed 256 and patch_dim in {256, 512, 1024, 2048} (got %d, %d)", embed, patch_dim);
     MPO_CHECK(total_rows >= 1, "patch weight gradient: no rows");
     MPO_CHECK((uint64_t)total_rows * (uint64_t)patch_dim * 2 < ((uint64_t)1 << 32), "patch weight gradient: patch matrix of 4 GiB or more");
     MPO_CHECK(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x)) & 15) == 0, "patch weight gradient: operands must be 16-byte aligned");
     const int n_cb = patch_dim / WG_CB;
-    const int ranges = WG_WGS / n_cb;                               // 64 row ranges at patch_dim 1024, 256 at 256
+    // workgroups = 0: one per CU.  Fewer (a multiple of 8 n_cb, e.g. 224 of 256 at patch_dim 1024) leave CUs to a kernel of
+    // another stream -- the gradient all-reduce of a data-parallel step: a persistent kernel that owns
+    // every CU's LDS and registers lets nothing else run until its workgroups retire.
+    MPO_CHECK(workgroups == 0 || (workgroups >= 8 * n_cb && workgroups <= WG_WGS && workgroups % (8 * n_cb) == 0),
+              "patch weight gradient: workgroups must be 0 or a multiple of %d up to %d (got %d)", 8 * n_cb, WG_WGS, workgroups);
+    const int ranges = (workgroups ? workgroups : WG_WGS) / n_cb;   // 64 row ranges at patch_dim 1024, 256 at 256
     const int rpr = ((total_rows + ranges - 1) / ranges + WG_BK - 1) / WG_BK * WG_BK;
     patch_wgrad_kernel<<<ranges * n_cb, WG_WAVES * 64, 0, stream>>>(static_cast<const __bf16*>(g), static_cast<const __bf16*>(x),
                                                                   total_rows, patch_dim, rpr, part);

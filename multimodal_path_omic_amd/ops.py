@@ -19,6 +19,10 @@ from . import _lib as L
 # Upper bound on the workgroups of a window's work plan (None: one per CU).  A measurement knob (tools/gpu_probe_overlap.py):
 # persistent bag kernels on fewer CUs leave the rest to whatever another stream launches.
 plan_workgroups = None
+# Workgroups of the patch layer's weight-gradient kernel (None / 0: one per CU).  A data-parallel step sets 224: the kernel is
+# persistent and owns its CUs outright, so the gradient all-reduce that runs beside it on another stream needs CUs of its own
+# (measured with tools/gpu_probe_dp_overlap.py).
+wgrad_workgroups = None
 
 
 @dataclass
@@ -412,7 +416,10 @@ def patch_weight_grad(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> to
             and g.is_contiguous() and x.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32):
         lib = L.lib()
         ws = _workspace(lib.mpo_patch_weight_grad_workspace_bytes(e, k), g.device)
-        L.check(lib.mpo_patch_weight_grad(L.ptr(g), L.ptr(x), g.shape[0], e, k, L.ptr(out), L.ptr(ws), ws.numel(),
+        wgs = int(wgrad_workgroups or 0)
+        if wgs and k != 1024:
+            wgs = 0                                        # (the setting is for the patch layer's own gradient, patch_dim 1024)
+        L.check(lib.mpo_patch_weight_grad(L.ptr(g), L.ptr(x), g.shape[0], e, k, L.ptr(out), wgs, L.ptr(ws), ws.numel(),
                                           L.stream_of(g)), "mpo_patch_weight_grad")
         return out
     return _splitk_tn(g, x, out)

@@ -75,6 +75,66 @@ def test_two_rank_allreduce_equals_single_process(tmp_path):
         torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
 
 
+def _worker_n(rank, world, port, out, strong):
+    """One optimiser step of the data-parallel path at world size N on the cfg-4 multiset (32 slides per rank, or 32 in all
+    with `strong`), dealt by assign_slides; the toy model stands in for the kernels, the exchange is the product's."""
+    from multimodal_path_omic_amd.synthetic import slide_lengths
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = _model()
+    bucket = FlatGradBucket(list(model.parameters()))
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    n_global = 32 if strong else 32 * world
+    lengths = slide_lengths(n_global, 2000, 30000, 4321)
+    mine = assign_slides(lengths, world)[rank]
+    g = torch.Generator().manual_seed(7)
+    feats = torch.randn(n_global, 8, generator=g)                 # one feature row per slide (its length only weighs the split)
+    bucket.begin()
+    for i in mine:
+        # every slide carries 1 / (global window): ranks may hold different COUNTS (the split balances patches, not slides),
+        # so the per-rank scale is world / n_global and the exchange takes the mean over ranks
+        (_loss(model, feats[i:i + 1]) * (world / n_global)).backward()
+    bucket.finish()
+    bucket.all_reduce_mean()
+    opt.step()
+    if rank == 0:
+        torch.save([p.detach().clone() for p in model.parameters()], out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world,strong", [(4, False), (8, False), (4, True), (8, True)],
+                         ids=["world4_weak", "world8_weak", "world4_strong", "world8_strong"])
+def test_exchange_at_world_4_and_8_equals_single_process(tmp_path, world, strong):
+    """the data-parallel step at N = 4 and 8 on the fixed 2k-30k multiset of BASELINE config 4 -- the
+    length-aware split leaves the slowest rank within 5 % of the mean load, and bucket + one all-reduce reproduce the
+    single-process update over the global window; `strong` keeps the global window at 32 slides (the reference's
+    grad_acc_step, models/mcat/main.py:69-74: the optimiser's trajectory does not change with N), weak grows it with N."""
+    from multimodal_path_omic_amd.synthetic import slide_lengths
+    n_global = 32 if strong else 32 * world
+    lengths = slide_lengths(n_global, 2000, 30000, 4321)
+    parts = assign_slides(lengths, world)
+    assert sorted(i for p in parts for i in p) == list(range(n_global))
+    loads = [sum(lengths[i] for i in p) for p in parts]
+    mean = sum(loads) / world
+    imbalance = max(loads) / mean - 1.0
+    print(f"[dp] world {world} {'strong' if strong else 'weak'}: {n_global} slides, load max/mean - 1 = {imbalance:.3%}")
+    assert imbalance <= 0.05, imbalance                           # (measured: 0.04 % .. 1.3 %)
+    port, out = _free_port(), str(tmp_path / "p.pt")
+    mp.spawn(_worker_n, args=(world, port, out, strong), nprocs=world, join=True)
+    got = torch.load(out, weights_only=True)
+    model = _model()
+    g = torch.Generator().manual_seed(7)
+    feats = torch.randn(n_global, 8, generator=g)
+    for i in range(n_global):
+        (_loss(model, feats[i:i + 1]) / n_global).backward()
+    torch.optim.SGD(model.parameters(), lr=0.1).step()
+    for a, b in zip(got, model.parameters()):
+        torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
 def test_bucket_views_alias_param_grads():
     model = _model()
     bucket = FlatGradBucket(list(model.parameters()))

@@ -77,7 +77,8 @@ def test_non_finite_features_stay_non_finite(dev):
     keep = torch.ones(rows, dtype=torch.bool, device=dev)
     keep[7] = keep[300] = False
     assert torch.isfinite(h[keep]).all()
-    assert torch.equal(h[keep], clean[keep])
+    # (not bit-equal: with an infinity in the window feature_scale() falls back to 1, the clean window is scaled by its maximum)
+    torch.testing.assert_close(h[keep], clean[keep], rtol=0, atol=5e-6)
 
 
 def test_dropout_mask_lives_in_the_output_and_gates_the_backward(dev):
