@@ -175,5 +175,7 @@ def model_inputs(m, omic_sizes, seed):
 
 
 # cohort run: slides, M range, epochs, grad_acc_step, seed
-COHORT = dict(n_slides=40, m_lo=256, m_hi=1024, epochs=2, grad_acc_step=8, seed=901,
+# (SURVEY 8(c) planned 64 slides, M <= 2 048, 3 epochs, 80/20: 80 slides make the split integral -- 64 train slides = 8 whole
+#  accumulation windows of 8, 16 validation slides)
+COHORT = dict(n_slides=80, m_lo=256, m_hi=2048, epochs=3, grad_acc_step=8, seed=901,
               weight_seed=902, omic_sizes=[64] * 6, lr=2e-4, weight_decay=1e-5, train_frac=0.8)

@@ -1,7 +1,9 @@
 """Seeded synthetic-cohort run: the reference's train()/validate() loop, restated in
 multimodal-path-omic_amd/harness.py around the HIP model (dropout off, fixed slide order, fixed 80/20
 split, Adam lr 2e-4 wd 1e-5, grad_acc_step 8), must reproduce the per-slide risks the REFERENCE produced
-(tests/golden/cohort.npz) and therefore the same C-index on the fixed split."""
+(tests/golden/cohort.npz: 80 slides of 256..2048 patches, 64 train / 16 validation, 3 epochs = 24 optimiser steps) and
+therefore the same C-index on the fixed split -- with fp32 bags (the reference's storage) AND with the bf16 bag storage the
+bench line runs in (models/mcat/main.py:56,81: risk = -sum(survs), concordance over the epoch's risks)."""
 import numpy as np
 import pytest
 import torch
@@ -29,14 +31,31 @@ def _near_tie_slack(event, time, ref_risk, gap):
     return close / max(comparable, 1)
 
 
+# What the per-slide risks may differ by from the fp32 REFERENCE's, by model and bag storage.  fp32 bags: the forward parity
+# bar before the first optimiser step, then what Adam's g / sqrt(v) makes of last-bit gradient differences (NaCAGaT's
+# trajectory is ill-conditioned in the reference algorithm itself: the CPU oracle's own validation risks move by 5e-3 / 1.4e-2
+# under a 1e-5 relative perturbation of the patch features, MCAT's by 1.5e-6 -- tools/cpu_cohort_sensitivity.py).  bf16 bags:
+# before the first optimiser step the storage floor of the mode (measured, r04: 5e-5 on MCAT's risks); behind Adam steps a
+# 1e-3-relative perturbation of the bag is amplified like any other (early Adam updates are lr * sign-like g / sqrt(v): small
+# gradient components flip) -- measured drift of the per-slide risks (|risk| ~ 1-1.7) against the fp32 REFERENCE over the 24
+# steps: 0.03 / 0.07 / 0.13 per epoch for both models.  What has to survive is the ranking: the C-index, held to the
+# reference's within the near-tie slack AND within 0.05 absolute (measured: final epoch equal on train and validation for
+# MCAT, 0.9326 / 0.9319 train and 0.8082 / 0.8219 validation -- one of 73 comparable pairs -- for NaCAGaT; worst epoch 0.041).
+FIRST_WINDOW_TOL = {("mcat", "f32"): 1e-3, ("nacagat", "f32"): 1e-3, ("mcat", "bf16"): 1e-3, ("nacagat", "bf16"): 3e-3}
+TRAJ_TOL = {("mcat", "f32"): 5e-3, ("nacagat", "f32"): 2e-2, ("mcat", "bf16"): 0.25, ("nacagat", "bf16"): 0.25}
+C_INDEX_ABS_BF16 = 0.05
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])
-def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kind):
+def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kind, storage):
+    bag_dtype = torch.float32 if storage == "f32" else torch.bfloat16
     g = golden("cohort")
     cfg = C.COHORT
     slides = syn.make_cohort(cfg["n_slides"], cfg["m_lo"], cfg["m_hi"], cfg["omic_sizes"], cfg["seed"])
     n_train = int(cfg["train_frac"] * len(slides))
     cls = MultimodalCoAttentionTransformer if kind == "mcat" else NarrowContextualAttentionGateTransformer
-    model = cls(omic_sizes=cfg["omic_sizes"])
+    model = cls(omic_sizes=cfg["omic_sizes"], bag_dtype=bag_dtype)
     model.load_state_dict(syn.fill_state_dict(C.model_shapes(cfg["omic_sizes"], kind == "nacagat"), cfg["weight_seed"]))
     model.to(dev).eval()                                       # dropout off, gradients on (as the generator)
     bucket = FlatGradBucket(list(model.parameters()))
@@ -48,7 +67,7 @@ def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kin
         risks, losses = [], []
         for w0 in range(0, n_train, acc):                      # one window = one optimiser step
             window = slides[w0:min(w0 + acc, n_train)]
-            bags, omics, labels, cens = harness.make_window(window, dev)
+            bags, omics, labels, cens = harness.make_window(window, dev, bag_dtype)
             bucket.begin()
             per_slide, risk = harness.train_window(model, bags, omics, labels, cens, acc)
             bucket.finish()
@@ -57,18 +76,17 @@ def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kin
             losses.append(per_slide.cpu())
         risks, losses = torch.cat(risks).numpy(), torch.cat(losses).numpy()
         ref_r, ref_l = g[f"{kind}/train_risk/{epoch}"].numpy(), g[f"{kind}/train_loss/{epoch}"].numpy()
-        # first epoch, first window: no optimiser step yet -> forward parity bar (1e-3)
+        # first epoch, first window: no optimiser step yet -> forward parity bar
         if epoch == 0:
-            assert np.abs(risks[:acc] - ref_r[:acc]).max() < 1e-3
-        # later slides sit behind Adam steps, which amplify last-bit gradient differences (g / sqrt(v)).  NaCAGaT's
-        # trajectory is ill-conditioned in the reference algorithm itself: the CPU oracle's own validation risks move
-        # by 5e-3 (epoch 0) / 1.4e-2 (epoch 1) under a 1e-5 relative perturbation of the patch features, MCAT's by
-        # 1.5e-6 (tools/cpu_cohort_sensitivity.py) -- hence the two bars.
-        traj_tol = 2e-2 if kind == "nacagat" else 5e-3
+            first = np.abs(risks[:acc] - ref_r[:acc]).max()
+            print(f"[cohort {kind} {storage}] first window |risk - ref| {first:.2e}")
+            assert first < FIRST_WINDOW_TOL[kind, storage], first
+        traj_tol = TRAJ_TOL[kind, storage]
+        print(f"[cohort {kind} {storage}] epoch {epoch}: train |risk - ref| {np.abs(risks - ref_r).max():.2e}, loss {np.abs(losses - ref_l).max():.2e}")
         assert np.abs(risks - ref_r).max() < traj_tol, np.abs(risks - ref_r).max()
         assert np.abs(losses - ref_l).max() < traj_tol
         with torch.no_grad():
-            bags, omics, _, _ = harness.make_window(slides[n_train:], dev)
+            bags, omics, _, _ = harness.make_window(slides[n_train:], dev, bag_dtype)
             _, sv, _, _ = model.forward_window(bags, omics)
             val = harness.risk_score(sv).cpu().numpy()
         ref_v = g[f"{kind}/val_risk/{epoch}"].numpy()
@@ -80,6 +98,10 @@ def test_cohort_training_reproduces_reference_risks_and_c_index(dev, golden, kin
             ci = harness.concordance_index_censored(ev, tm, ours)
             ci_ref = harness.concordance_index_censored(ev, tm, ref)
             slack = _near_tie_slack(ev, tm, ref, 2 * np.abs(ours - ref).max())
-            if kind == "mcat":
-                slack = 0.0                                     # well-conditioned: exact equality
+            if kind == "mcat" and storage == "f32":
+                slack = 0.0                                     # well-conditioned, the reference's storage: exact equality
+            print(f"[cohort {kind} {storage}] epoch {epoch}: C-index {ci:.4f} (reference {ci_ref:.4f}), near-tie slack {slack:.4f}, "
+                  f"val |risk - ref| {np.abs(val - ref_v).max():.2e}")
             assert abs(ci - ci_ref) <= slack + 1e-12, (ci, ci_ref, slack)
+            if storage == "bf16":
+                assert abs(ci - ci_ref) <= C_INDEX_ABS_BF16, (ci, ci_ref)

@@ -221,6 +221,36 @@ def test_full_size_bf16_training_window_equals_per_slide(dev, kind):
         assert float((grads_w[k] - p.grad).abs().max()) / scale < bar, k
 
 
+def test_whole_model_at_100k_fp32_patches_matches_oracle(dev):
+    """BASELINE config 5 as ONE model: a 100 000 x 1024 fp32 slide through MCAT medium -- the fp32 patch
+    layer (fp16-split MFMA products, patch_fc_f32.hip), K1's forward over the fp32 H_bag, the tail, `ces`, K1's vector backward,
+    the one-pass fp32 weight gradient -- against the CPU oracle on the same slide: hazards, the co-attention map (sampled
+    columns), a sample of dW_H rows and the patch layer's bias gradient.  (The per-kernel tests hold each of these kernels at
+    this size alone; the bench runs the chain unchecked.)"""
+    sizes, m = [256] * 6, 100_000
+    wsi, omics, label, censor = C.model_inputs(m, sizes, 51)
+    sd = syn.fill_state_dict(C.model_shapes(sizes, False), 52)
+    model = MultimodalCoAttentionTransformer(omic_sizes=sizes)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    hz, sv, y, att = model(wsi=wsi.to(dev), omics=[o.to(dev) for o in omics], inference=True)
+    ces_loss(hz, sv, label.to(dev), censor.to(dev)).backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hz_o, sv_o, _, att_o = O.mcat_forward(p, wsi, omics, inference=True)
+    O.ces_loss(hz_o, sv_o, label, censor).backward()
+    e_h = float((hz.detach().cpu() - hz_o).abs().max())
+    cols = torch.randint(0, m, (4096,), generator=torch.Generator().manual_seed(3))
+    a, a_o = att["coattn"].detach().cpu()[:, cols], att_o["coattn"].detach()[:, cols]
+    e_a = float(((a - a_o).abs() / a_o.abs().clamp_min(1e-30)).max())
+    g, g_o = model.H[0].weight.grad.cpu(), p["H.0.weight"].grad
+    rows = torch.arange(0, 256, 8)
+    e_w = float((g[rows] - g_o[rows]).abs().max() / g_o.abs().max())
+    gb, gb_o = model.H[0].bias.grad.cpu(), p["H.0.bias"].grad
+    e_b = float((gb - gb_o).abs().max() / gb_o.abs().max())
+    print(f"[cfg5 whole model] hazards {e_h:.1e}, map rel {e_a:.1e}, dW_H rows {e_w:.1e}, db_H {e_b:.1e}")
+    assert e_h < 1e-4 and e_a < 1e-3 and e_w < 5e-3 and e_b < 5e-3, (e_h, e_a, e_w, e_b)
+
+
 @pytest.mark.parametrize("kind", ["mcat", "nacagat"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_small_model_size_matches_oracle(dev, kind, dtype):
