@@ -291,7 +291,6 @@ def _bias_grad_slot(bag_param, E, dev):
 defer_patch_weight_grad = False
 _deferred_patch = []
 
-
 def flush_patch_weight_grads():
     """Compute the patch-layer weight gradients PatchFcFn.backward queued (into the bucket slices it already returned)."""
     for g, x, dw in _deferred_patch:
