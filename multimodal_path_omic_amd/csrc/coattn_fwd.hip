@@ -150,12 +150,21 @@ void coattn_fwd_partial_kernel(const void* __restrict__ bag_, const int* __restr
         constexpr int kWaitNext = (NI & 15) | ((NI >> 4) << 14) | 0x0F70;
         constexpr int kWaitAll = 0x0F70;
         char* img1 = thi + G::TILEB;
-        if (n_my > 0) issue(t0row, thi);
+        // The tiles of a range are walked from its END (MPO_K1_FWD_FORWARD_WALK: from its start): in the window step this pass
+        // follows the patch-layer kernel, whose workgroups wrote H_bag front to back -- the rows written last are the ones
+        // the caches still hold, and a front-to-back read would evict them with the rows it misses on.  (The online softmax
+        // does not care about the order.)
+#ifdef MPO_K1_FWD_FORWARD_WALK
+        const int tfirst = t0row, tstep = tstride;
+#else
+        const int tfirst = t0row + (n_my - 1) * tstride, tstep = -tstride;
+#endif
+        if (n_my > 0) issue(tfirst, thi);
         for (int it = 0; it < n_my; ++it) {
-            const int trow = t0row + it * tstride;
+            const int trow = tfirst + it * tstep;
             char* cur = (it & 1) ? img1 : thi;
             if (it + 1 < n_my) {
-                issue(trow + tstride, (it & 1) ? thi : img1);     // its last readers finished with the previous tile
+                issue(trow + tstep, (it & 1) ? thi : img1);       // its last readers finished with the previous tile
                 __builtin_amdgcn_s_waitcnt(kWaitNext);
             } else {
                 __builtin_amdgcn_s_waitcnt(kWaitAll);
