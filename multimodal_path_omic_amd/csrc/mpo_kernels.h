@@ -266,6 +266,19 @@ int mpo_launch_mha_small_fwd(const float* qkv, float* o, float* p_save, int B, i
                              hipStream_t s);
 int mpo_launch_mha_small_bwd(const float* qkv, const float* p_save, const float* d_o, float* dqkv, int B, int T, int d, int H,
                              hipStream_t s);
+// the pooling head's scorer (attention_c: d -> 1) per branch, for the kernels that fold it into the pooling (token tail)
+struct PoolScorer {
+    const float* wc[2] = {nullptr, nullptr};      // attention_c.weight [1][d]
+    const float* bc[2] = {nullptr, nullptr};      // attention_c.bias [1]
+    float* dwc[2] = {nullptr, nullptr};           // their gradients (backward)
+    float* dbc[2] = {nullptr, nullptr};
+    int n_slides = 1;                             // slides per branch
+};
+int mpo_launch_pool_score_fwd(const float* a, const float* b, const float* x, const PoolScorer& ps, float* scores, float* w,
+                              float* h, int B, int L, int d, hipStream_t s);
+int mpo_launch_pool_score_bwd(const float* dh, const float* x, const float* w, const float* d_ext, const float* a, const float* b,
+                              const PoolScorer& ps, float* d_scores, float* dx, float* da, float* db, int B, int L, int d,
+                              hipStream_t s);
 int mpo_launch_pool_fwd(const float* scores, const float* x, float* w, float* h, int B, int L, int d, hipStream_t s);
 int mpo_launch_pool_bwd(const float* dh, const float* x, const float* w, const float* d_ext, float* d_scores, float* dx,
                         int B, int L, int d, hipStream_t s);

@@ -419,6 +419,85 @@ void pool_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x, 
     }
 }
 
+// ---- the pooling head's scorer folded into the pooling kernels (token tail, L <= 64): scores_l = (a_l (.) b_l) . w_c + b_c is six
+// dot products per slide and branch -- as its own 256 -> 1 product it was a launch on the general (guarded) GEMM body plus an
+// a * b pass before it, and in the backward a second grouped launch plus a dab * b / dab * a pass (models/blocks.py:42-48,
+// models/mcat/mcat.py:105-107).  One workgroup per (branch, slide).
+__global__ __launch_bounds__(256)
+void pool_score_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bg, const float* __restrict__ x, PoolScorer ps,
+                           float* __restrict__ scores, float* __restrict__ w, float* __restrict__ h, int L, int d) {
+    __shared__ float sc[64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int br = b / ps.n_slides;
+    const float* wc = ps.wc[br];
+    for (int l = wv; l < L; l += 4) {                             // one wave per token row
+        const size_t row = ((size_t)b * L + l) * d;
+        float v = 0.f;
+        for (int c = lane; c < d; c += 64) v += a[row + c] * bg[row + c] * wc[c];
+        v = wave_sum(v);
+        if (lane == 0) {
+            v += ps.bc[br][0];
+            sc[l] = v;
+            scores[(size_t)b * L + l] = v;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int l = 0; l < L; ++l) mx = fmaxf(mx, sc[l]);
+    float sum = 0.f;
+    for (int l = 0; l < L; ++l) sum += __expf(sc[l] - mx);
+    const float inv = 1.0f / sum;
+    if (tid < L) w[(size_t)b * L + tid] = __expf(sc[tid] - mx) * inv;
+    for (int c = tid; c < d; c += 256) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc += __expf(sc[l] - mx) * inv * x[((size_t)b * L + l) * d + c];
+        h[(size_t)b * d + c] = acc;
+    }
+}
+
+// d_scores of one slide into ds[0..L) (LDS): ds_l = w_l (dh . x_l - sum_k w_k dh . x_k) + d_ext_l
+__device__ __forceinline__ void pool_dscores(const float* __restrict__ dhb, const float* __restrict__ x, const float* __restrict__ w,
+                                             const float* __restrict__ d_ext, size_t b, int L, int d, float* ds, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int l = wv; l < L; l += 4) {
+        float v = 0.f;
+        for (int c = lane; c < d; c += 64) v += dhb[c] * x[(b * L + l) * d + c];
+        v = wave_sum(v);
+        if (lane == 0) ds[l] = v;
+    }
+    __syncthreads();
+    float dl = 0.f;
+    for (int l = 0; l < L; ++l) dl += w[b * L + l] * ds[l];
+    __syncthreads();
+    if (tid < L) ds[tid] = w[b * L + tid] * (ds[tid] - dl) + (d_ext ? d_ext[b * L + tid] : 0.f);
+    __syncthreads();
+}
+// per slide: d_scores, dx = w_l dh, da = d_scores w_c (.) b, db = d_scores w_c (.) a.  (The scorer's own gradients,
+// dW_c = sum_rows d_scores (a (.) b) and db_c = sum_rows d_scores, need every slide's d_scores: they ride in the launch that
+// follows, tail_api.hip -- computed here by one workgroup per branch walking its 32 slides they took 130 us.)
+__global__ __launch_bounds__(256)
+void pool_score_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ w,
+                           const float* __restrict__ d_ext, const float* __restrict__ a, const float* __restrict__ bg, PoolScorer ps,
+                           float* __restrict__ d_scores, float* __restrict__ dx, float* __restrict__ da, float* __restrict__ db,
+                           int L, int d) {
+    __shared__ float ds[64];
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int br = (int)b / ps.n_slides;
+    const float* dhb = dh + b * d;
+    const float* wc = ps.wc[br];
+    pool_dscores(dhb, x, w, d_ext, b, L, d, ds, tid);
+    if (tid < L) d_scores[b * L + tid] = ds[tid];
+    for (int it = tid; it < L * d; it += 256) {
+        const int l = it / d, c = it % d;
+        const size_t i = (b * L + l) * d + c;
+        const float g = ds[l] * wc[c];
+        dx[i] = w[b * L + l] * dhb[c];
+        da[i] = g * bg[i];
+        db[i] = g * a[i];
+    }
+}
+
 // ---- the same pooling over a LONG axis (L = the M rows of a bag: models/ge_nacagat/ge_nacagat.py:56-58).  The kernels above
 // give one workgroup a whole slide and walk L serially; here L is spread over the grid.
 // w = softmax_L(scores): one workgroup of 1024 threads per slide
@@ -830,6 +909,21 @@ int mpo_launch_pool_fwd(const float* scores, const float* x, float* w, float* h,
     } else {
         pool_fwd_kernel<<<B, 256, 0, s>>>(scores, x, w, h, L, d);
     }
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_pool_score_fwd(const float* a, const float* b, const float* x, const PoolScorer& ps, float* scores, float* w,
+                              float* h, int B, int L, int d, hipStream_t s) {
+    MPO_CHECK(L >= 1 && L <= 64 && B % ps.n_slides == 0, "fused pooling scorer: 1..64 rows per slide (got %d)", L);
+    pool_score_fwd_kernel<<<B, 256, 0, s>>>(a, b, x, ps, scores, w, h, L, d);
+    MPO_LAUNCH_CHECK();
+    return 0;
+}
+int mpo_launch_pool_score_bwd(const float* dh, const float* x, const float* w, const float* d_ext, const float* a, const float* b,
+                              const PoolScorer& ps, float* d_scores, float* dx, float* da, float* db, int B, int L, int d,
+                              hipStream_t s) {
+    MPO_CHECK(L >= 1 && L <= 64 && B % ps.n_slides == 0, "fused pooling scorer backward: 1..64 rows per slide (got %d)", L);
+    pool_score_bwd_kernel<<<B, 256, 0, s>>>(dh, x, w, d_ext, a, b, ps, d_scores, dx, da, db, L, d);
     MPO_LAUNCH_CHECK();
     return 0;
 }

@@ -310,10 +310,10 @@ uint64_t mpo_gated_pool_rng_span(int n_slides, int L, int d) { return 3 * ((uint
 
 // AttentionNetGated (models/blocks.py:13-48) + the pooling idiom of models/mcat/mcat.py:105-109:
 // scores = W_c[drop(tanh(W_a x)) * drop(sigmoid(W_b x))] + b_c; h = drop(relu(W_rho (softmax_L(scores) x) + b_rho))
-// The gate product a (.) b of the pooling head (models/blocks.py:42-48) is formed on the scorer's A operand and its
-// gradients in the scorer's backward launch for the token tail's row counts; long bags (row f3: L = M rows) keep the
-// three element-wise passes, whose many-row GEMM forms they share a launch sequence with.
-static bool pool_fuses_gate_product(int rows_per_branch) { return rows_per_branch <= 512; }
+// The pooling head's scorer (models/blocks.py:42-48: attention_c on a (.) b) runs inside the pooling kernels for the token
+// tail (<= 64 rows per slide, <= 2 branches); long bags (row f3: L = M rows) keep the grid-wide pooling kernels and the
+// scorer as a many-row product.
+static bool pool_fuses_scorer(int n_branches, int L, int d) { return n_branches <= 2 && L <= 64 && d <= 1024; }
 
 int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, int d, const float* const* params,
                            float head_drop_p, float rho_drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
@@ -329,20 +329,13 @@ int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, 
     auto P = [&](int br, int i) { return params[br * 8 + i]; };
     const DropSpec s0 = stream_of(head_drop_p, seed, offset, stride, 0, rng_epoch), s1 = stream_of(head_drop_p, seed, offset, stride, 1, rng_epoch),
                    s2 = stream_of(rho_drop_p, seed, offset, stride, 2, rng_epoch);
-    const bool fuse_ab = pool_fuses_gate_product(R);
+    const bool fuse_ab = pool_fuses_scorer(NB, L, d);
     GroupBuilder gab, gsc, grho;
     for (int br = 0; br < NB; ++br) {
         RC(gab.add(mpo_args_fwd(x + br * Rd, P(br, 0), P(br, 1), a + br * Rd, R, d, d, 1.0f, MPO_ACT_TANH, nullptr, drop_br(s0, br, Rd))));
         RC(gab.add(mpo_args_fwd(x + br * Rd, P(br, 2), P(br, 3), b + br * Rd, R, d, d, 1.0f, MPO_ACT_SIGMOID, nullptr, drop_br(s1, br, Rd))));
-        if (fuse_ab) {
-            // scores = (a (.) b) W_c^T + b_c with the product formed on the A operand (value gate "multiply by b"): no a * b pass
-            GemmArgs sc = mpo_args_fwd(a + br * Rd, P(br, 4), P(br, 5), scores + (size_t)br * R, R, d, 1, 1.0f, MPO_ACT_NONE);
-            sc.gate = b + br * Rd;
-            sc.gate_mode = MPO_GATE_MUL;
-            RC(gsc.add(sc));
-        } else {
+        if (!fuse_ab)
             RC(gsc.add(mpo_args_fwd(ab + br * Rd, P(br, 4), P(br, 5), scores + (size_t)br * R, R, d, 1, 1.0f, MPO_ACT_NONE)));
-        }
         if (h_interleaved) {
             // h [n_slides][branch][d] = the concatenated [h_path | h_omic] rows the fusion layer reads (no transposing copy);
             // one dropout stream over the interleaved rows: branch br starts d / 4 counters in
@@ -358,9 +351,17 @@ int mpo_gated_pool_forward(const float* x, int n_branches, int n_slides, int L, 
         }
     }
     RC(gab.launch(stream));
-    if (!fuse_ab) RC(mpo_launch_ew_mul(a, b, ab, RT * d, stream));
-    RC(gsc.launch(stream));
-    RC(mpo_launch_pool_fwd(scores, x, w, hpool, BT, L, d, stream));
+    if (fuse_ab) {
+        // scores = (a (.) b) W_c^T + b_c, softmax over the slide's rows and the weighted sum in ONE launch
+        PoolScorer ps;
+        for (int br = 0; br < NB; ++br) { ps.wc[br] = P(br, 4); ps.bc[br] = P(br, 5); }
+        ps.n_slides = n_slides;
+        RC(mpo_launch_pool_score_fwd(a, b, x, ps, scores, w, hpool, BT, L, d, stream));
+    } else {
+        RC(mpo_launch_ew_mul(a, b, ab, RT * d, stream));
+        RC(gsc.launch(stream));
+        RC(mpo_launch_pool_fwd(scores, x, w, hpool, BT, L, d, stream));
+    }
     RC(grho.launch(stream));
     return 0;
 }
@@ -398,32 +399,14 @@ int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L,
     const int h_ld = h_interleaved ? NB * d : d;
     RC(pairs([&](int br) { GemmArgs m = mpo_args_bwd_input(dh + br * h_off, P(br, 6), dhpool + br * Bd, n_slides, d, d, 1.0f, 0, gate(h + br * h_off, MPO_GATE_RELU, rho_drop_p)); m.lda = h_ld; return m; },
              [&](int br) { GemmArgs m = mpo_args_bwd_weight(dh + br * h_off, hpool + br * Bd, G(br, 6), G(br, 7), n_slides, d, d, 1.0f, gate(h + br * h_off, MPO_GATE_RELU, rho_drop_p)); m.lda = h_ld; return m; }));
-    RC(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, BT, L, d, stream));
-    if (pool_fuses_gate_product(R)) {
-        // scores = (a (.) b) W_c^T + b_c, backward in ONE launch and without the a * b / dab * b / dab * a passes:
-        //   da = (dscores W_c) (.) b and db = (dscores W_c) (.) a: the input-gradient product twice, the other factor as the
-        //        epilogue's output mask;
-        //   dW_c^T [d x 1] = (a (.) b)^T dscores: a as the (row-contiguous) A operand with the value gate "multiply by b";
-        //   db_c = sum(dscores): the bias-gradient side output of a 1 x 1 weight-gradient product (its dW goes to scratch).
-        float* scratch = dab;                                      // (the a * b gradient itself is never formed)
-        GroupBuilder gsc;
-        for (int br = 0; br < NB; ++br) {
-            const float* ds = dscores + (size_t)br * R;
-            GemmArgs m1 = mpo_args_bwd_input(ds, P(br, 4), da + br * Rd, R, d, 1, 1.0f, 0);
-            m1.mask = b + br * Rd;
-            GemmArgs m2 = mpo_args_bwd_input(ds, P(br, 4), db + br * Rd, R, d, 1, 1.0f, 0);
-            m2.mask = a + br * Rd;
-            GemmArgs m3;
-            m3.A = a + br * Rd; m3.lda = d;                        // A(m = column j, k = row r) = a[r][j]
-            m3.gate = b + br * Rd; m3.gate_mode = MPO_GATE_MUL;
-            m3.B = ds; m3.ldb = 1;                                 // B(n = 0, k = r) = dscores[r]
-            m3.C = G(br, 4); m3.ldc = 1;
-            m3.M = d; m3.N = 1; m3.K = R; m3.layout = 0;
-            GemmArgs m4 = mpo_args_bwd_weight(ds, ds, scratch + br, G(br, 5), R, 1, 1, 1.0f);
-            RC(gsc.add(m1)); RC(gsc.add(m2)); RC(gsc.add(m3)); RC(gsc.add(m4));
-        }
-        RC(gsc.launch(stream));
+    if (pool_fuses_scorer(NB, L, d)) {
+        // pooling + scorer backward in ONE launch: d_scores, dx (pooling part), da, db (dW_c, db_c: below)
+        PoolScorer ps;
+        for (int br = 0; br < NB; ++br) { ps.wc[br] = P(br, 4); ps.bc[br] = P(br, 5); }
+        ps.n_slides = n_slides;
+        RC(mpo_launch_pool_score_bwd(dhpool, x, w, d_scores_ext, a, b, ps, dscores, dx, da, db, BT, L, d, stream));
     } else {
+        RC(mpo_launch_pool_bwd(dhpool, x, w, d_scores_ext, dscores, dx, BT, L, d, stream));
         // scores = ab W_c^T + b_c
         RC(pairs([&](int br) { return mpo_args_bwd_input(dscores + (size_t)br * R, P(br, 4), dab + br * Rd, R, d, 1, 1.0f, 0); },
                  [&](int br) { return mpo_args_bwd_weight(dscores + (size_t)br * R, ab + br * Rd, G(br, 4), G(br, 5), R, d, 1, 1.0f); }));
@@ -438,6 +421,20 @@ int mpo_gated_pool_backward(const float* x, int n_branches, int n_slides, int L,
             RC(second.add(mpo_args_bwd_input(db + br * Rd, P(br, 2), dx + br * Rd, R, d, d, 1.0f, 1, gb)));
             RC(first.add(mpo_args_bwd_weight(da + br * Rd, x + br * Rd, G(br, 0), G(br, 1), R, d, d, 1.0f, ga)));
             RC(first.add(mpo_args_bwd_weight(db + br * Rd, x + br * Rd, G(br, 2), G(br, 3), R, d, d, 1.0f, gb)));
+            if (pool_fuses_scorer(NB, L, d)) {
+                // the scorer's own gradients ride in the second launch:
+                //   dW_c^T [d x 1] = (a (.) b)^T d_scores: a as the (row-contiguous) A operand with the value gate "multiply by b";
+                //   db_c = sum(d_scores): the bias-gradient side output of a 1 x 1 weight-gradient product (its dW goes to scratch)
+                const float* ds = dscores + (size_t)br * R;
+                GemmArgs m3;
+                m3.A = a + br * Rd; m3.lda = d;                    // A(m = column j, k = row r) = a[r][j]
+                m3.gate = b + br * Rd; m3.gate_mode = MPO_GATE_MUL;
+                m3.B = ds; m3.ldb = 1;                             // B(n = 0, k = r) = d_scores[r]
+                m3.C = G(br, 4); m3.ldc = 1;
+                m3.M = d; m3.N = 1; m3.K = R; m3.layout = 0;
+                RC(second.add(m3));
+                RC(second.add(mpo_args_bwd_weight(ds, ds, dab + br, G(br, 5), R, 1, 1, 1.0f)));
+            }
         }
         RC(first.launch(stream));
         RC(second.launch(stream));
