@@ -152,18 +152,21 @@ def _time_launches(dev, launch, reps, burst=4, between=None):
     return sorted(s.elapsed_time(e) * 1e3 / burst for s, e in evs), burst
 
 
-def _stored_profile(name, avg_us, applies):
-    """PMC-derived fields come from a STORED profile of the same kernel on the same configuration (profiles/<name>:
-    separate rocprofv3 --pmc passes, FETCH_SIZE x 2 per the gfx950 correction), not from this run: labelled as such."""
-    path = os.path.join(ROOT, "profiles", name)
-    if not (applies and os.path.exists(path)):
+def _stored_profile(kernel_key, avg_us):
+    """PMC-derived fields come from a STORED profile of the same kernel inside the same workload (profiles/r04_traffic.json:
+    separate rocprofv3 --pmc passes over the eager window step, FETCH_SIZE x 2 per the gfx950 correction), not from this run:
+    labelled as such.  Returns (hbm bytes per launch, matrix-pipe busy share, source)."""
+    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    if not os.path.exists(path):
         return None, None, None
     with open(path) as f:
-        prof = json.load(f)
-    busy = prof.get("mfma", {}).get("SQ_VALU_MFMA_BUSY_CYCLES")
-    # PMC busy cycles (summed over SIMDs) against this run's measured launch time
+        prof = json.load(f).get(kernel_key)
+    if not prof:
+        return None, None, None
+    busy = prof.get("SQ_VALU_MFMA_BUSY_CYCLES")
+    # PMC busy cycles (summed over SIMDs) against this run's measured launch time, priced at the 2.4 GHz peak clock
     util = round(busy / (4 * 256 * avg_us * 1e-6 * 2.4e9), 4) if busy else None
-    return prof.get("hbm_bytes_per_launch"), util, "profiles/" + name
+    return prof.get("hbm_bytes_per_launch"), util, "profiles/r04_traffic.json <- " + prof.get("pmc_file", "")
 
 
 def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=None):
@@ -203,7 +206,6 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=
                                                      plan, stream.cuda_stream), "mpo_patch_coattn_fwd_bagpass")
         alg_bytes = window * patches * (1024 + E) * 2
         name = "patch_fc_fwd_kernel<1024->256, bf16>"
-        tname = "f1_fwd_traffic.json"
         applies = window == 32 and patches == 15000
     else:
         k2 = kind == "nacagat"
@@ -225,13 +227,12 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=
                                                    stream.cuda_stream), "mpo_coattn_fwd_bagpass")
         alg_bytes = window * patches * E * esz
         name = "bag_rowdot_gated_exact_kernel<256> (f32 key bag)" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
-        tname = "k2_fwd_traffic.json" if k2 else "k1_fwd_traffic.json"
-        applies = window == 32 and patches == 15000 and (k2 or esz == 2)
+        applies = (window == 32 and patches == 15000) or (window == 8 and patches == 100000 and esz == 4 and not k2)
     extra = {"timing": "each launch preceded by one replay of the window step"} if between is not None else {}
     us, burst = _time_launches(dev, launch, reps, between=between)
     avg_us = sum(us) / len(us)
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    traffic, mfma_util, source = _stored_profile(tname, avg_us, applies)
+    traffic, mfma_util, source = _stored_profile(name, avg_us) if applies else (None, None, None)
     if fused:
         # the cross-attention proper (north_star: "the 15k-patch cross-attention kernel"): K1's forward bag pass over the bf16 H_bag
         hb = [torch.relu(torch.randn(window * patches, E, device=dev)).to(torch.bfloat16) for _ in range(2)]
@@ -243,7 +244,9 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=
         us1, burst1 = _time_launches(dev, launch_k1, reps, between=between)
         a1 = sum(us1) / len(us1)
         b1 = window * patches * E * 2
+        t1, u1, s1 = _stored_profile("coattn_fwd_partial_kernel<256,bf16>", a1) if applies else (None, None, None)
         extra["cross_attention"] = {"kernel": "coattn_fwd_partial_kernel<256,bf16>", "bound": "hbm", "algorithmic_bytes_per_launch": b1,
+                                    "traffic": t1, "mfma_util": u1, "traffic_source": s1,
                                     "avg_launch_us": round(a1, 2), "min_launch_us": round(us1[0], 2),
                                     "achieved": round(b1 / (a1 * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(b1 / (a1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "launches_timed": reps * burst1}
