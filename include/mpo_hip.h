@@ -105,7 +105,9 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
                                   mpo_stream_t stream);
 /* The patch layer alone: h_bag [total_rows, embed] bf16 = dropout(relu(patches W^T + b)) (models/mcat/mcat.py:24-29,87), one
  * pass of the fused kernel with its co-attention slices off (NaCAGaT needs H_bag for more than one product; MCAT outside
- * the fused configuration).  Same dropout stream and realised rate as mpo_patch_coattn_mcat_forward. */
+ * the fused configuration).  Same dropout stream and realised rate as mpo_patch_coattn_mcat_forward.
+ * patch_dim 1024; embed 128 / 256 / 512 = model_size small / medium / big (models/mcat/mcat.py:16-21) on the one kernel:
+ * 128 as a 256-column block whose upper half is not stored, 512 as one pass per 256-column half.  Other widths: error. */
 size_t mpo_patch_fc_workspace_bytes(int embed, int patch_dim);
 int mpo_patch_fc_forward(const void* patches, const int32_t* cu_rows, int n_slides, int total_rows, int max_rows, int patch_dim,
                          const float* patch_weight, const float* patch_bias, int embed, float drop_p, uint64_t seed,
@@ -131,7 +133,8 @@ int mpo_patch_fc_f32_backward(const float* d_h_bag, const float* h_bag /* nullab
                               size_t workspace_bytes, mpo_stream_t stream);
 
 /* The fused bag pass alone (measurement): w_packed = embed * patch_dim bf16 values from mpo_pack_patch_weight (the weight
- * in the fragment order of the kernel's GEMM waves), qk2 [n_slides*n_q, embed]. */
+ * in the fragment order of the kernel's GEMM waves; one 512-KiB block per 256 rows of W_H, embed 128: one block whose upper
+ * half is zero), qk2 [n_slides*n_q, embed].  The bag pass is the embed-256 form. */
 int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_packed, const float* bias, const int32_t* cu_rows, int n_slides,
                                  const float* qk2, void* h_bag, float* part_ml, float* part_ctx, int n_q, int max_rows,
                                  float drop_p, uint64_t seed, uint64_t offset, const mpo_bag_plan* plan /* nullable */,
@@ -161,8 +164,9 @@ int mpo_coattn_mcat_backward(const void* bag, int bag_dtype, const int32_t* cu_r
  * in LDS when dH is formed, which saves two passes over the bag gradient. */
 
 /* ---- epilogue of the patch layer self.H (models/mcat/mcat.py:24-29): h = dropout_p(relu(h + bias)) in place on the
- * bf16 GEMM output [rows, cols], and its derivative g = dy * (h > 0 ? 1/(1-p) : 0).  The GEMM itself stays a library
- * call.  Backward: n = rows * cols elements; d_bias (nullable, [cols]) receives the column
+ * bf16 product [rows, cols], and its derivative g = dy * (h > 0 ? 1/(1-p) : 0).  (The forward half dates from r01, when the
+ * product X W^T was a library call; mpo_patch_fc_forward has covered every model width since ABI v13 and the Python host no
+ * longer calls it.)  Backward: n = rows * cols elements; d_bias (nullable, [cols]) receives the column
  * sums of g -- the layer's bias gradient -- from the same pass (workspace of *_workspace_bytes then required). */
 int mpo_patch_epilogue_forward(void* h_bf16, const float* bias, int64_t rows, int cols, float drop_p, uint64_t seed,
                                uint64_t offset, const uint64_t* rng_epoch, mpo_stream_t stream);
@@ -176,7 +180,9 @@ int mpo_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, mpo_
  * g^T X over the whole window, g [rows, embed] bf16 = gradient w.r.t. the layer's pre-activation (what
  * mpo_coattn_mcat_backward with bag_relu_gate / mpo_nacagat_patch_grad / mpo_patch_epilogue_backward emit), X the raw bf16
  * patch matrix.  Hand-written split-row kernel (one workgroup per CU, fp32 partials in the workspace + a reduction
- * launch).  Built for embed 256 and patch_dim a multiple of 256 (256 ... 2048).
+ * launch).  Built for embed 128 / 256 / 512 (512: one pass per 256 columns of g) and patch_dim 128, 256, 512, 1024 or 2048
+ * (the narrow ones: NaCAGaT's key-projection weight gradient d_k^T H_bag); any number of rows -- the kernel's DMA offsets
+ * are 32-bit, 4 GiB of patches and more go in row segments whose partial sums accumulate.  Other geometries: error.
  * workgroups (ABI v13): 0 = one per CU (256); fewer -- a multiple of 8 * patch_dim / 256, e.g. 224 at patch_dim 1024 -- leave
  * CUs free for a kernel of ANOTHER stream: the gradient all-reduce that a data-parallel step runs beside this product. */
 size_t mpo_patch_weight_grad_workspace_bytes(int embed, int patch_dim);

@@ -206,7 +206,7 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
     if ((rc = mpo_launch_pack_patch_weight(patch_weight, w_bf16, E, patch_dim, stream))) return rc;
     if ((rc = mpo_linear_fwd(query, in_w, in_b, qs, R, E, E, scale, MPO_ACT_NONE, stream))) return rc;
     if ((rc = mpo_linear_bwd_input(qs, in_w + (size_t)E * E, qk2, R, E, E, kLog2e, 0, stream))) return rc;
-    if ((rc = mpo_launch_patch_fc_fwd(patches, w_bf16, patch_bias, cu_rows, h_bag, drop_p, seed, offset,
+    if ((rc = mpo_launch_patch_fc_fwd(patches, w_bf16, patch_bias, cu_rows, h_bag, E, drop_p, seed, offset,
                                       reinterpret_cast<const unsigned long long*>(rng_epoch), plan, stream))) return rc;
     if ((rc = mpo_launch_coattn_fwd_partial(h_bag, 0, cu_rows, n_slides, E, qk2, part_ml, part_ctx, attn_map, n_q, plan, stream))) return rc;
     if ((rc = mpo_launch_coattn_combine(part_ml, part_ctx, ctx, lse2, n_slides, n_q, E, plan, stream))) return rc;
@@ -220,21 +220,23 @@ int mpo_patch_coattn_mcat_forward(const void* patches, const int32_t* cu_rows, i
 // The patch layer alone, H_bag = dropout(relu(X W_H^T + b_H)) (models/mcat/mcat.py:24-29,87), as ONE pass of the same
 // kernel with its co-attention slices switched off: for the models whose co-attention needs more than H_bag (NaCAGaT's
 // key projection) and for MCAT outside the fused configuration.  Workspace: the packed bf16 copy of the weight.
-size_t mpo_patch_fc_workspace_bytes(int embed, int patch_dim) { return (size_t)embed * patch_dim * 2 + 256; }
+size_t mpo_patch_fc_workspace_bytes(int embed, int patch_dim) { return (size_t)(embed < 256 ? 256 : embed) * patch_dim * 2 + 256; }
 int mpo_patch_fc_forward(const void* patches, const int32_t* cu_rows, int n_slides, int total_rows, int max_rows, int patch_dim,
                          const float* patch_weight, const float* patch_bias, int embed, float drop_p, uint64_t seed,
                          uint64_t offset, const uint64_t* rng_epoch, void* h_bag, const mpo_bag_plan* plan_, void* workspace,
                          size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(MPO_BF16, n_slides, total_rows, max_rows, 1, embed)) return rc;
-    MPO_CHECK(embed == 256 && patch_dim == 1024, "patch layer kernel is built for 1024 -> 256 (got %d -> %d)", patch_dim, embed);
+    MPO_CHECK((embed == 128 || embed == 256 || embed == 512) && patch_dim == 1024,
+              "patch layer kernel is built for 1024 -> 128, 256 or 512 (got %d -> %d)", patch_dim, embed);
+    MPO_CHECK((int64_t)max_rows * embed * 2 < ((int64_t)1 << 31), "patch layer: a slide's H_bag of 2 GiB or more (%d rows)", max_rows);
     const BagPlan plan = make_plan(plan_, n_slides, max_rows);
     if (int rc = check_plan(plan, n_slides)) return rc;
     Arena ws(workspace, workspace_bytes);
-    float* w_bf16 = ws.floats((size_t)embed * patch_dim / 2);
+    float* w_bf16 = ws.floats((size_t)(embed < 256 ? 256 : embed) * patch_dim / 2);
     MPO_CHECK(w_bf16, "patch layer: workspace too small (%zu bytes)", workspace_bytes);
     int rc;
     if ((rc = mpo_launch_pack_patch_weight(patch_weight, w_bf16, embed, patch_dim, stream))) return rc;
-    return mpo_launch_patch_fc_fwd(patches, w_bf16, patch_bias, cu_rows, h_bag, drop_p, seed, offset,
+    return mpo_launch_patch_fc_fwd(patches, w_bf16, patch_bias, cu_rows, h_bag, embed, drop_p, seed, offset,
                                    reinterpret_cast<const unsigned long long*>(rng_epoch), plan, stream);
 }
 
@@ -271,7 +273,7 @@ int mpo_patch_coattn_fwd_bagpass(const void* patches, const void* w_packed, cons
                                  float drop_p, uint64_t seed, uint64_t offset, const mpo_bag_plan* plan_, mpo_stream_t stream) {
     const BagPlan plan = make_plan(plan_, n_slides, max_rows);
     if (int rc = check_plan(plan, n_slides)) return rc;
-    if (int rc = mpo_launch_patch_fc_fwd(patches, w_packed, bias, cu_rows, h_bag, drop_p, seed, offset, nullptr, plan, stream)) return rc;
+    if (int rc = mpo_launch_patch_fc_fwd(patches, w_packed, bias, cu_rows, h_bag, 256, drop_p, seed, offset, nullptr, plan, stream)) return rc;
     if (qk2 == nullptr) return 0;
     return mpo_launch_coattn_fwd_partial(h_bag, 0, cu_rows, n_slides, 256, qk2, part_ml, part_ctx, nullptr, n_q, plan, stream);
 }
@@ -702,7 +704,7 @@ int mpo_patch_weight_grad(const void* g_bf16, const void* patches_bf16, int64_t 
     Arena ws(workspace, workspace_bytes);
     float* part = ws.floats(mpo_patch_wgrad_partial_floats(embed, patch_dim));
     MPO_CHECK(part, "patch weight gradient: workspace too small (%zu bytes)", workspace_bytes);
-    return mpo_launch_patch_wgrad(g_bf16, patches_bf16, (int)total_rows, embed, patch_dim, part, d_weight, workgroups,
+    return mpo_launch_patch_wgrad(g_bf16, patches_bf16, total_rows, embed, patch_dim, part, d_weight, workgroups,
                                   static_cast<hipStream_t>(stream));
 }
 

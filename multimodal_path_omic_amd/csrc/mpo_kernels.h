@@ -140,7 +140,7 @@ struct BagPlan;
 extern "C" int mpo_coattn_splits(int n_slides, int max_rows);
 // rows H2 / f1: the patch layer of a bf16 window, 1024 -> 256, one pass over the raw patch matrix (patch_fc_fwd.hip)
 int mpo_launch_pack_patch_weight(const float* w, void* out, int embed, int patch_dim, hipStream_t stream);
-int mpo_launch_patch_fc_fwd(const void* x, const void* w_packed, const float* bias, const int* cu, void* h_out, float drop_p,
+int mpo_launch_patch_fc_fwd(const void* x, const void* w_packed, const float* bias, const int* cu, void* h_out, int embed, float drop_p,
                             unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
                             const BagPlan& plan, hipStream_t stream);
 int mpo_launch_coattn_fwd_partial(const void* bag, int bag_f32, const int* cu, int n_slides, int embed,
@@ -183,7 +183,7 @@ int mpo_launch_k2_patch_grad(const int* cu, const void* dk_bf16, const float* w_
 int mpo_gemm_fast_path(int enabled);   // gemm_f32.hip: returns the previous setting
 // dW_H = g^T X of the patch layer, hand-written (patch_wgrad.hip): part = mpo_patch_wgrad_partial_floats() floats
 size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim);
-int mpo_launch_patch_wgrad(const void* g_bf16, const void* x_bf16, int total_rows, int embed, int patch_dim, float* part,
+int mpo_launch_patch_wgrad(const void* g_bf16, const void* x_bf16, int64_t total_rows, int embed, int patch_dim, float* part,
                            float* d_weight, int workgroups, hipStream_t stream);
 // what follows a split-M bag pass, one launch: up to two per-slide reductions of [parts][n_q*E] partials, the column
 // sums over all partials of a [parts][cs_cols] array, zero-fills of up to two regions (coattn_bwd.hip: bag_finish_kernel)

@@ -119,14 +119,20 @@ __device__ __forceinline__ int chunk_rotation(int c) { return (8 * (c >> 1) + SK
 __device__ float mpo_pf_stamps[1024 * 16];     // per workgroup: wave 0 -> [0..7], wave 4 -> [8..15]
 #endif
 
+// WIDTH = embed_dim of the model (models/mcat/mcat.py:16-21: 128 'small', 256, 512 'big'), the row pitch of H_bag.  The pass
+// always works on a 256-column block of W_H: WIDTH 128 = the block's upper half is zero rows of the packed weight and the
+// waves that own it (cq 2, 3) aim their stores past the buffer's range; WIDTH 512 = two passes, columns col_off = 0 and 256.
+template <int WIDTH>
 __global__ __launch_bounds__(NTHREADS, 2)
 void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows][1024] patch features
-                         const __bf16* __restrict__ wb,           // W_H rounded to bf16, packed in stage order (pack_patch_weight_kernel)
-                         const float* __restrict__ bias,          // [256]
+                         const __bf16* __restrict__ wb,           // the pass's 256 rows of W_H as bf16, packed in stage order (pack_patch_weight_kernel)
+                         const float* __restrict__ bias,          // [WIDTH]
                          const int* __restrict__ cu,
-                         __bf16* __restrict__ h_out,              // [total_rows][256]
+                         __bf16* __restrict__ h_out,              // [total_rows][WIDTH]
+                         int col_off,                             // first embed column of this pass
                          float drop_p, unsigned long long seed, unsigned long long offset_,
                          const unsigned long long* __restrict__ epoch, BagPlan plan) {
+    constexpr int NCQ = WIDTH < PE ? WIDTH / 64 : 4;              // waves of a stream whose 64 columns exist
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,7 +170,9 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
     f32x4 bk[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-        bk[dt] = *reinterpret_cast<const f32x4*>(bias + 64 * (wave & 3) + 32 * (dt >> 1) + 8 * (lane >> 4) + 4 * (dt & 1));
+        bk[dt] = (wave & 3) < NCQ
+            ? *reinterpret_cast<const f32x4*>(bias + col_off + 64 * (wave & 3) + 32 * (dt >> 1) + 8 * (lane >> 4) + 4 * (dt & 1))
+            : f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the plain loads above must not sit in front of the rings)
     const unsigned long long offset = epoch_offset(offset_, epoch);
     const uint32_t drop_key = hash_stream_key(seed, offset);      // (the stream offset is in the key: the counter below is the element group alone)
@@ -178,8 +186,10 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
     const char* wpk = reinterpret_cast<const char*>(wb);
     const unsigned lds0 = lds_addr(lds);
     // H_bag of this slide as a buffer whose range ends at the workgroup's last row: stores to rows >= r1 are dropped
+    // (a pass over columns col_off .. + 255 of a wider H_bag: base moved by col_off, range shortened by as much)
     const __amdgpu_buffer_rsrc_t hbuf = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(h_out) + (size_t)row_begin * (PE * 2), 0, (int)((unsigned)r1 * (PE * 2)), 0x00020000);
+        reinterpret_cast<char*>(h_out) + (size_t)row_begin * (WIDTH * 2) + col_off * 2, 0,
+        (int)((unsigned)r1 * (WIDTH * 2) - (unsigned)col_off * 2), 0x00020000);
 
     int gs = 0;                                                   // global stage
     // X pair q (main stages 2 q, 2 q + 1) of chunk j of this stream: rows r0 + CH (2 j + st) .. + 127 x 128 B at k-steps
@@ -265,7 +275,7 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
         const int row = r0 + CH * (2 * j + st) + 16 * PT + ei;    // slide-relative
         uint32_t rw[4] = {0u, 0u, 0u, 0u};
         if (drop_p > 0.f) {                                       // one draw = the 16 bytes of this lane's 16 elements of the row
-            const uint4 rnd = hash16(drop_key, drop_inc, (uint32_t)(row_begin + row) * 16u + (uint32_t)(4 * cq + eg));
+            const uint4 rnd = hash16(drop_key, drop_inc, (uint32_t)(row_begin + row) * (uint32_t)(WIDTH / 16) + (uint32_t)(col_off / 16 + 4 * cq + eg));
             rw[0] = rnd.x; rw[1] = rnd.y; rw[2] = rnd.z; rw[3] = rnd.w;
         }
         typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -283,7 +293,8 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
             o[dt >> 1][2 * (dt & 1)] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e[0], e[1]}, bf16x2));
             o[dt >> 1][2 * (dt & 1) + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{e[2], e[3]}, bf16x2));
         }
-        const unsigned voff = (unsigned)row * (PE * 2) + (unsigned)((8 * cq + eg) << 4);
+        const unsigned voff = cq < NCQ ? (unsigned)row * (WIDTH * 2) + (unsigned)((8 * cq + eg) << 4)
+                                       : 0xFFFFFF00u;            // (columns that do not exist: out of the buffer's range, dropped -- the store still counts)
         __builtin_amdgcn_raw_buffer_store_b128(o[0], hbuf, voff, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(o[1], hbuf, voff + 64, 0, 0);
     };
@@ -438,15 +449,19 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
 // lane (i = lane & 15, g = lane >> 4), holds W_H[64 cq + 32 (dt >> 1) + 8 (i >> 2) + 4 (dt & 1) + (i & 3)][32 s + 8 g .. + 7]: the
 // A operand (row i of embed tile (cq, dt), k-group g) of k-step s, with the tile's rows permuted so that the MFMA result
 // leaves lane group g with embed columns 64 cq + 32 (dt >> 1) + 8 g + 4 (dt & 1) + r.
-__global__ void pack_patch_weight_kernel(const float* __restrict__ w, bf16x8* __restrict__ out) {
+// Rows >= rows_valid (the 'small' model: 128 rows of W_H) are packed as zeros.
+__global__ void pack_patch_weight_kernel(const float* __restrict__ w, bf16x8* __restrict__ out, int rows_valid) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte fragment per thread: 256 * 1024 / 8 of them
     if (t >= PE * PK / 8) return;
     const int lane = t & 63, blk = t >> 6;
     const int dt = blk & 3, cq = (blk >> 2) & 3, s = blk >> 4;
     const int i = lane & 15, g = lane >> 4;
     const int row = 64 * cq + 32 * (dt >> 1) + 8 * (i >> 2) + 4 * (dt & 1) + (i & 3), k0 = 32 * s + 8 * g;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)row * PK + k0);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)row * PK + k0 + 4);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (row < rows_valid) {
+        a = *reinterpret_cast<const f32x4*>(w + (size_t)row * PK + k0);
+        b = *reinterpret_cast<const f32x4*>(w + (size_t)row * PK + k0 + 4);
+    }
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -464,22 +479,39 @@ extern "C" int mpo_debug_patch_fc_stamps(float* host) {
 }
 #endif
 
+// out: one 512-KiB packed block per 256 rows of W_H (embed 128: one block, upper half zero; 512: two blocks)
 int mpo_launch_pack_patch_weight(const float* w, void* out, int embed, int patch_dim, hipStream_t stream) {
-    MPO_CHECK(embed == PE && patch_dim == PK, "patch weight packing is built for %d x %d (got %d x %d)", PE, PK, embed, patch_dim);
-    pack_patch_weight_kernel<<<PE * PK / 8 / 256, 256, 0, stream>>>(w, reinterpret_cast<bf16x8*>(out));
-    MPO_LAUNCH_CHECK();
+    MPO_CHECK((embed == 128 || embed == 256 || embed == 512) && patch_dim == PK,
+              "patch weight packing is built for {128, 256, 512} x %d (got %d x %d)", PK, embed, patch_dim);
+    for (int c0 = 0; c0 < embed; c0 += PE) {
+        pack_patch_weight_kernel<<<PE * PK / 8 / 256, 256, 0, stream>>>(w + (size_t)c0 * PK, reinterpret_cast<bf16x8*>(out) + (size_t)c0 * PK / 8,
+                                                                      min(PE, embed - c0));
+        MPO_LAUNCH_CHECK();
+    }
     return 0;
 }
 
-int mpo_launch_patch_fc_fwd(const void* x, const void* w_packed, const float* bias, const int* cu, void* h_out, float drop_p,
+int mpo_launch_patch_fc_fwd(const void* x, const void* w_packed, const float* bias, const int* cu, void* h_out, int embed, float drop_p,
                             unsigned long long seed, unsigned long long offset, const unsigned long long* epoch,
                             const BagPlan& plan, hipStream_t stream) {
+    MPO_CHECK(embed == 128 || embed == 256 || embed == 512, "patch layer: embed_dim %d not in {128, 256, 512}", embed);
     MPO_CHECK(drop_p >= 0.f && drop_p < 1.f, "patch-layer dropout p must be in [0,1) (got %f)", (double)drop_p);
     MPO_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(h_out)) & 15) == 0,
               "patch layer: operands must be 16-byte aligned");
-    patch_fc_fwd_kernel<<<plan_grid(plan), NTHREADS, 0, stream>>>(
-        reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(w_packed), bias, cu,
-        reinterpret_cast<__bf16*>(h_out), drop_p, seed, offset, epoch, plan);
+    const __bf16* xb = reinterpret_cast<const __bf16*>(x);
+    const __bf16* wp = reinterpret_cast<const __bf16*>(w_packed);
+    __bf16* hb = reinterpret_cast<__bf16*>(h_out);
+    if (embed == 128) {
+        patch_fc_fwd_kernel<128><<<plan_grid(plan), NTHREADS, 0, stream>>>(xb, wp, bias, cu, hb, 0, drop_p, seed, offset, epoch, plan);
+    } else if (embed == 256) {
+        patch_fc_fwd_kernel<256><<<plan_grid(plan), NTHREADS, 0, stream>>>(xb, wp, bias, cu, hb, 0, drop_p, seed, offset, epoch, plan);
+    } else {
+        for (int c0 = 0; c0 < 512; c0 += PE) {                    // (the patch matrix is read once per column half)
+            patch_fc_fwd_kernel<512><<<plan_grid(plan), NTHREADS, 0, stream>>>(xb, wp + (size_t)c0 * PK, bias, cu, hb, c0, drop_p, seed, offset,
+                                                                              epoch, plan);
+            MPO_LAUNCH_CHECK();
+        }
+    }
     MPO_LAUNCH_CHECK();
     return 0;
 }

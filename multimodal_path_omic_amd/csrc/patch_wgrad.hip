@@ -45,13 +45,15 @@ __device__ __forceinline__ void wait_vm(int n) {
 
 __global__ __launch_bounds__(WG_WAVES * 64, 1)
 void patch_wgrad_kernel(const __bf16* __restrict__ g, const __bf16* __restrict__ x, int total_rows, int patch_dim,
+                        int g_dim,          // columns of g (its row pitch): 128, 256 or 512; this pass takes 256 of them from g on
+                        int e_rows,         // of which exist: 128 (g_dim 128: the image's upper half repeats the lower, its dW rows are not written) or 256
                         int rows_per_range, float* __restrict__ part) {
     using G = TileGeom<WG_E>;
     __shared__ __attribute__((aligned(1024))) char lds[WG_LDS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // workgroup id -> (row range, column block): the column blocks of a row range share an XCD (id mod 8)
-    const int n_cb = patch_dim / WG_CB;
+    const int n_cb = patch_dim < WG_CB ? 1 : patch_dim / WG_CB;    // (a 128-wide X: one block whose upper half repeats the lower and is not written)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int rr = xcd + 8 * (slot / n_cb), cb = slot % n_cb;
     const int rb = min(total_rows, rr * rows_per_range), re = min(total_rows, rb + rows_per_range);
@@ -60,7 +62,8 @@ void patch_wgrad_kernel(const __bf16* __restrict__ g, const __bf16* __restrict__
     // this wave's four wave-instructions of a chunk: instruction q = 4 wave + i fills KiB (q & 15) of image (q >> 4)
     const bool x_tile = wave >= 4;
     const char* src_base = x_tile ? reinterpret_cast<const char*>(x) + (size_t)cb * WG_CB * 2 : reinterpret_cast<const char*>(g);
-    const size_t src_row = x_tile ? (size_t)patch_dim * 2 : (size_t)WG_E * 2;
+    const size_t src_row = x_tile ? (size_t)patch_dim * 2 : (size_t)g_dim * 2;
+    const int cmask = x_tile ? (patch_dim < WG_CB ? patch_dim / 8 - 1 : 31) : e_rows / 8 - 1;      // 16-byte chunks of a source row that exist
     // (32-bit byte offsets against a scalar base: the launcher checks that the operands stay below 4 GiB)
     const unsigned src_row32 = (unsigned)src_row;
     auto issue = [&](int chunk) {
@@ -69,7 +72,7 @@ void patch_wgrad_kernel(const __bf16* __restrict__ g, const __bf16* __restrict__
         for (int i = 0; i < 4; ++i) {
             const int k = 4 * (wave & 3) + i;
             const int r = 2 * k + (lane >> 5), cs = lane & 31;
-            const int c = cs ^ ((r & 7) << 1);
+            const int c = (cs ^ ((r & 7) << 1)) & cmask;
             const int grow = min(rb + chunk * WG_BK + r, total_rows - 1);      // past the end: clamped, the g rows are zeroed below
             const unsigned off = (unsigned)grow * src_row32 + (unsigned)(c * 16);
             const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(stage + k * 1024);
@@ -164,8 +167,9 @@ void patch_wgrad_kernel(const __bf16* __restrict__ g, const __bf16* __restrict__
             mma(qa, qb);
         }
     }
-    // partial [rr][256][patch_dim]: lane holds rows 16 (4 wm + i) + 4 (lane >> 4) + r, column 16 (8 wn + j) + (lane & 15)
-    float* out = part + ((size_t)rr * WG_E) * patch_dim + (size_t)cb * WG_CB;
+    // partial [rr][e_rows][patch_dim]: lane holds rows 16 (4 wm + i) + 4 (lane >> 4) + r, column 16 (8 wn + j) + (lane & 15)
+    if (64 * wm >= e_rows || 128 * wn >= patch_dim) return;
+    float* out = part + ((size_t)rr * e_rows) * patch_dim + (size_t)cb * WG_CB;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -177,10 +181,11 @@ void patch_wgrad_kernel(const __bf16* __restrict__ g, const __bf16* __restrict__
 
 // dW[i] = sum_rr part[rr][i]: one float4 per thread, the 64 loads in flight eight at a time
 __global__ __launch_bounds__(256)
-void patch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n4, int n_parts) {
+void patch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n4, int n_parts, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) a = *reinterpret_cast<const f32x4*>(out + (size_t)i * 4);      // (a later row segment of the same window)
 #pragma unroll 8
     for (int s = 0; s < n_parts; ++s) a += *reinterpret_cast<const f32x4*>(part + ((size_t)s * n4 + i) * 4);
     *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = a;
@@ -190,29 +195,41 @@ void patch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict
 
 size_t mpo_patch_wgrad_partial_floats(int embed, int patch_dim) {
     const int n_cb = patch_dim / WG_CB > 0 ? patch_dim / WG_CB : 1;
-    return (size_t)(WG_WGS / n_cb) * embed * patch_dim;
+    return (size_t)(WG_WGS / n_cb) * (embed < WG_E ? embed : WG_E) * patch_dim;
 }
 
-int mpo_launch_patch_wgrad(const void* g, const void* x, int total_rows, int embed, int patch_dim, float* part, float* d_weight,
+// g [total_rows][embed] bf16, x [total_rows][patch_dim] bf16 -> d_weight [embed][patch_dim] fp32 (overwritten).  embed 512: one pass
+// per 256 columns of g; a patch matrix of 4 GiB or more (the kernel's DMA offsets are 32-bit): one pass per row segment.
+int mpo_launch_patch_wgrad(const void* g, const void* x, int64_t total_rows, int embed, int patch_dim, float* part, float* d_weight,
                            int workgroups, hipStream_t stream) {
-    MPO_CHECK(embed == WG_E && patch_dim >= WG_CB && patch_dim % WG_CB == 0 && (256 % (patch_dim / WG_CB)) == 0,
-              "patch weight gradient: built for embed 256 and patch_dim in {256, 512, 1024, 2048} (got %d, %d)", embed, patch_dim);
+    MPO_CHECK((embed == 128 || embed == 256 || embed == 512) &&
+              (patch_dim == 128 || (patch_dim >= WG_CB && patch_dim % WG_CB == 0 && (256 % (patch_dim / WG_CB)) == 0)),
+              "patch weight gradient: built for embed in {128, 256, 512} and patch_dim in {128, 256, 512, 1024, 2048} (got %d, %d)", embed, patch_dim);
     MPO_CHECK(total_rows >= 1, "patch weight gradient: no rows");
-    MPO_CHECK((uint64_t)total_rows * (uint64_t)patch_dim * 2 < ((uint64_t)1 << 32), "patch weight gradient: patch matrix of 4 GiB or more");
     MPO_CHECK(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x)) & 15) == 0, "patch weight gradient: operands must be 16-byte aligned");
-    const int n_cb = patch_dim / WG_CB;
+    const int n_cb = patch_dim < WG_CB ? 1 : patch_dim / WG_CB;
     // workgroups = 0: one per CU.  Fewer (a multiple of 8 n_cb, e.g. 224 of 256 at patch_dim 1024) leave CUs to a kernel of
     // another stream -- the gradient all-reduce of a data-parallel step: a persistent kernel that owns
     // every CU's LDS and registers lets nothing else run until its workgroups retire.
     MPO_CHECK(workgroups == 0 || (workgroups >= 8 * n_cb && workgroups <= WG_WGS && workgroups % (8 * n_cb) == 0),
               "patch weight gradient: workgroups must be 0 or a multiple of %d up to %d (got %d)", 8 * n_cb, WG_WGS, workgroups);
     const int ranges = (workgroups ? workgroups : WG_WGS) / n_cb;   // 64 row ranges at patch_dim 1024, 256 at 256
-    const int rpr = ((total_rows + ranges - 1) / ranges + WG_BK - 1) / WG_BK * WG_BK;
-    patch_wgrad_kernel<<<ranges * n_cb, WG_WAVES * 64, 0, stream>>>(static_cast<const __bf16*>(g), static_cast<const __bf16*>(x),
-                                                                  total_rows, patch_dim, rpr, part);
-    MPO_LAUNCH_CHECK();
-    const int n4 = embed * patch_dim / 4;
-    patch_wgrad_reduce_kernel<<<(n4 + 255) / 256, 256, 0, stream>>>(part, d_weight, n4, ranges);
-    MPO_LAUNCH_CHECK();
+    const int e_rows = embed < WG_E ? embed : WG_E;
+    const int wide = patch_dim > embed ? patch_dim : embed;
+    const int64_t seg_rows = ((((int64_t)1 << 32) - 1) / ((int64_t)wide * 2)) / WG_BK * WG_BK;      // rows whose byte offsets stay below 4 GiB
+    const __bf16* gb = static_cast<const __bf16*>(g);
+    const __bf16* xb = static_cast<const __bf16*>(x);
+    for (int64_t s0 = 0; s0 < total_rows; s0 += seg_rows) {
+        const int rows = (int)(total_rows - s0 < seg_rows ? total_rows - s0 : seg_rows);
+        const int rpr = ((rows + ranges - 1) / ranges + WG_BK - 1) / WG_BK * WG_BK;
+        for (int c0 = 0; c0 < embed; c0 += WG_E) {
+            patch_wgrad_kernel<<<ranges * n_cb, WG_WAVES * 64, 0, stream>>>(gb + (size_t)s0 * embed + c0, xb + (size_t)s0 * patch_dim, rows, patch_dim,
+                                                                          embed, e_rows, rpr, part);
+            MPO_LAUNCH_CHECK();
+            const int n4 = e_rows * patch_dim / 4;
+            patch_wgrad_reduce_kernel<<<(n4 + 255) / 256, 256, 0, stream>>>(part, d_weight + (size_t)c0 * patch_dim, n4, ranges, s0 > 0);
+            MPO_LAUNCH_CHECK();
+        }
+    }
     return 0;
 }

@@ -73,8 +73,8 @@ class _FusionModelBase(nn.Module):
             h = ops.patch_fc(x, lin.weight, lin.bias, p, pre_gated_grad=self._fused_bag_gate, batch=bags)
         elif ops.patch_fc_f32_supported(x, lin.weight):
             h = ops.patch_fc_f32(x, lin.weight, lin.bias, p)        # fp32 window, 1024 -> 256: hand-written both ways
-        else:                                                       # fp32 window of the small / big models: library GEMM
-            h = F.dropout(torch.relu(F.linear(x.float(), lin.weight, lin.bias)), p, self.training)
+        else:                                                       # fp32 window of the small / big models: the exact-fp32 MFMA GEMM (many-row form)
+            h = F.dropout(ops.linear(x.float(), lin.weight, lin.bias, "relu"), p, self.training)
         return bags.with_data(h)
 
     def _token_pair(self, bags: BagBatch, omics):

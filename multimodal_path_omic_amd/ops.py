@@ -162,7 +162,7 @@ def _workspace(nbytes, device):
 
 # ------------------------------------------------------------------------------------ linear
 class LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b) on the fp32 MFMA GEMM (stand-in for F.linear on the small-row tail)."""
+    """y = act(x W^T + b) on the fp32 MFMA GEMM (stands in for torch.nn.functional.linear on the small-row tail)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act: str = "none"):
@@ -191,15 +191,16 @@ class LinearFn(torch.autograd.Function):
             dy = dy * torch.where(y > 0, torch.ones_like(y), y + 1)
         dy = dy.contiguous()
         R, I, O = x2.shape[0], weight.shape[1], weight.shape[0]
-        dx = torch.empty_like(x2)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None      # (raw patch features take no gradient)
         dw = torch.empty_like(weight)
         db = torch.empty(O, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
         s = L.stream_of(dy)
-        L.check(L.lib().mpo_linear_backward_input(L.ptr(dy), L.ptr(weight), L.ptr(dx), R, I, O, 1.0, 0, s),
-                "mpo_linear_backward_input")
+        if dx is not None:
+            L.check(L.lib().mpo_linear_backward_input(L.ptr(dy), L.ptr(weight), L.ptr(dx), R, I, O, 1.0, 0, s),
+                    "mpo_linear_backward_input")
         L.check(L.lib().mpo_linear_backward_weight(L.ptr(dy), L.ptr(x2), L.ptr(dw), L.ptr(db), R, I, O, 1.0, s),
                 "mpo_linear_backward_weight")
-        return dx.view(ctx.xshape), dw, db, None
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db, None
 
 
 def linear(x, weight, bias=None, act="none"):
@@ -302,30 +303,26 @@ def flush_patch_weight_grads():
 class PatchFcFn(torch.autograd.Function):
     """H_bag = dropout_p(relu(X W_H^T + b)) for a bf16-stored window (models/mcat/mcat.py:24-29,87).
 
-    The two big GEMMs stay library calls (hipBLASLt through torch): forward X W^T, backward dW = g^T X.
-    What is ours: the fused bias + ReLU + dropout epilogue (one pass, mask regenerated from the counter
-    counter instead of stored) and the contraction over ~10^5-10^6 patch rows of dW, which hipBLASLt runs
-    on 16 workgroups when given as one GEMM: it is issued as a batched split-K product (fp32 partials)
-    and summed.  X never needs a gradient (it is data)."""
+    Forward: one pass of csrc/patch_fc_fwd.hip (embed 128 / 256 / 512: the same kernel, see its header), the dropout mask kept
+    in H_bag as zeros.  Backward: the ReLU / dropout derivative (in the consumer's kernel when it can, else one element-wise
+    pass) and dW_H = g^T X on csrc/patch_wgrad.hip.  X never needs a gradient (it is data).  Other geometries raise."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, drop_p: float, pre_gated_grad: bool, batch=None):
         lib = L.lib()
-        if batch is not None and patch_fc_kernel_supported(x, weight):
-            # one pass of the fused kernel with its co-attention slices off (no library GEMM, H_bag rounded once)
-            h = torch.empty(x.shape[0], weight.shape[0], device=x.device, dtype=torch.bfloat16)
-            seed, off = _reserve(h.numel() // 16 + 2) if drop_p > 0 else (0, 0)
-            ws = _workspace(lib.mpo_patch_fc_workspace_bytes(weight.shape[0], weight.shape[1]), x.device)
-            L.check(lib.mpo_patch_fc_forward(L.ptr(x), L.ptr(batch.cu), batch.n_slides, batch.total_rows, batch.max_rows,
-                                             x.shape[1], L.ptr(weight), L.ptr(bias), weight.shape[0], float(drop_p), seed, off,
-                                             _epoch(), L.ptr(h), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(x)),
-                    "mpo_patch_fc_forward")
-            drop_p = _realised_drop(drop_p) if drop_p > 0 else 0.0
-        else:
-            h = torch.mm(x, weight.to(torch.bfloat16).t())
-            seed, off = _reserve(h.numel() // 8 + 2) if drop_p > 0 else (0, 0)
-            L.check(lib.mpo_patch_epilogue_forward(L.ptr(h), L.ptr(bias), h.shape[0], h.shape[1], float(drop_p), seed, off,
-                                                   _epoch(), L.stream_of(h)), "mpo_patch_epilogue_forward")
+        if not patch_fc_kernel_supported(x, weight):
+            raise ValueError(f"patch layer: built for a contiguous bf16 window through Linear(1024, 128 | 256 | 512) "
+                             f"(got {x.dtype} {tuple(x.shape)} -> {weight.shape[0]})")
+        if batch is None:                   # a bare patch matrix: one slide
+            batch = BagBatch(x, make_cu([x.shape[0]], x.device), [x.shape[0]])
+        h = torch.empty(x.shape[0], weight.shape[0], device=x.device, dtype=torch.bfloat16)
+        seed, off = _reserve(h.numel() // 16 + 2) if drop_p > 0 else (0, 0)
+        ws = _workspace(lib.mpo_patch_fc_workspace_bytes(weight.shape[0], weight.shape[1]), x.device)
+        L.check(lib.mpo_patch_fc_forward(L.ptr(x), L.ptr(batch.cu), batch.n_slides, batch.total_rows, batch.max_rows,
+                                         x.shape[1], L.ptr(weight), L.ptr(bias), weight.shape[0], float(drop_p), seed, off,
+                                         _epoch(), L.ptr(h), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(x)),
+                "mpo_patch_fc_forward")
+        drop_p = _realised_drop(drop_p) if drop_p > 0 else 0.0
         ctx.save_for_backward(x, h)
         ctx.param_refs = (weight, bias)
         ctx.drop_p, ctx.pre_gated = float(drop_p), bool(pre_gated_grad)
@@ -377,51 +374,23 @@ def _colsum_two_stage(g: torch.Tensor, out: torch.Tensor, block: int = 256) -> t
     return out
 
 
-def _splitk_tn(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor, target_chunk: int = 0) -> torch.Tensor:
-    """g^T x with the (huge) row dimension split into batches: (S, d, C) @ (S, C, k) -> sum_S, fp32.
-    The batch count is chosen so that the library's 256 x 256 output tiles fill the 256 CUs exactly once
-    (480 000 x 256 x 1024: 64 batches of 7 500 rows = 284 us; 117 batches of 4 102 = 344 us; 29 of 16 551 = 663 us,
-    tools/gpu_time_splitk.py); target_chunk > 0 forces a chunk length instead."""
-    rows = g.shape[0]
-    if target_chunk > 0:
-        s = max(1, rows // target_chunk)
-    else:
-        tiles = -(-g.shape[1] // 256) * -(-x.shape[1] // 256)
-        s = max(1, 256 // tiles)
-        while s > 1 and rows // s < 1024:       # short bags: keep each batch a decent GEMM
-            s //= 2
-    c = rows // s
-    main = s * c
-    ga, xa = g[:main].view(s, c, -1).transpose(1, 2), x[:main].view(s, c, -1)
-    # r01 record (gpurun_out/fwdgemm.log, tools/README.md): a batched library GEMM given a stride-0 (expanded) operand
-    # faulted the GPU.  These are plain views of two dense matrices; refuse anything else before it reaches the library.
-    for t in (ga, xa):
-        if any(st == 0 and n > 1 for st, n in zip(t.stride(), t.shape)):
-            raise RuntimeError(f"split-K product: operand with a zero stride {tuple(t.stride())} for shape {tuple(t.shape)}")
-    part = torch.bmm(ga, xa, out_dtype=torch.float32)
-    torch.sum(part, 0, out=out)
-    if main < rows:
-        out += torch.mm(g[main:].t(), x[main:], out_dtype=torch.float32)
-    return out
-
-
 def patch_weight_grad(g: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """dW_H = g^T x into `out` (embed, patch_dim) fp32: the hand-written kernel (mpo_patch_weight_grad) for a bf16 window
-    at embed 256 / patch_dim 256, 512, 1024 or 2048 whose patch matrix stays below 4 GiB (the launcher's conditions:
-    32-bit DMA offsets, 256 row ranges per column block), the library split-K product otherwise."""
+    """dW_H = g^T x into `out` (embed, patch_dim) fp32 on csrc/patch_wgrad.hip: bf16 operands, embed 128 / 256 / 512,
+    patch_dim 128, 256, 512, 1024 or 2048, any number of rows (4 GiB of patches and more go in row segments).  Anything else raises."""
     e, k = out.shape
-    if (g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and e == 256 and k in (256, 512, 1024, 2048)
-            and g.shape[0] * k * 2 < 2 ** 32
+    if not (g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and e in (128, 256, 512) and k in (128, 256, 512, 1024, 2048)
+            and g.shape == (x.shape[0], e) and x.shape[1] == k
             and g.is_contiguous() and x.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32):
-        lib = L.lib()
-        ws = _workspace(lib.mpo_patch_weight_grad_workspace_bytes(e, k), g.device)
-        wgs = int(wgrad_workgroups or 0)
-        if wgs and k != 1024:
-            wgs = 0                                        # (the setting is for the patch layer's own gradient, patch_dim 1024)
-        L.check(lib.mpo_patch_weight_grad(L.ptr(g), L.ptr(x), g.shape[0], e, k, L.ptr(out), wgs, L.ptr(ws), ws.numel(),
-                                          L.stream_of(g)), "mpo_patch_weight_grad")
-        return out
-    return _splitk_tn(g, x, out)
+        raise ValueError(f"patch weight gradient: g {g.dtype} {tuple(g.shape)} x {x.dtype} {tuple(x.shape)} -> {tuple(out.shape)} is not a "
+                         f"geometry the kernel is built for (contiguous bf16, embed 128/256/512, patch_dim 128/256/512/1024/2048)")
+    lib = L.lib()
+    ws = _workspace(lib.mpo_patch_weight_grad_workspace_bytes(e, k), g.device)
+    wgs = int(wgrad_workgroups or 0)
+    if wgs and k != 1024:
+        wgs = 0                                        # (the setting is for the patch layer's own gradient, patch_dim 1024)
+    L.check(lib.mpo_patch_weight_grad(L.ptr(g), L.ptr(x), g.shape[0], e, k, L.ptr(out), wgs, L.ptr(ws), ws.numel(),
+                                      L.stream_of(g)), "mpo_patch_weight_grad")
+    return out
 
 
 class PatchFcF32Fn(torch.autograd.Function):
@@ -603,8 +572,8 @@ def fused_patch_coattn_supported(x, embed: int, n_q: int) -> bool:
 
 
 def patch_fc_kernel_supported(x, weight) -> bool:
-    """mpo_patch_fc_forward: a bf16 window through Linear(1024, 256)."""
-    return x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(weight.shape) == (256, 1024)
+    """mpo_patch_fc_forward: a bf16 window through Linear(1024, 128 | 256 | 512)."""
+    return x.dtype == torch.bfloat16 and x.is_contiguous() and weight.shape[0] in (128, 256, 512) and weight.shape[1] == 1024
 
 
 def patch_fc(x_bf16, weight, bias, drop_p: float, pre_gated_grad: bool = False, batch: "BagBatch | None" = None):
@@ -615,8 +584,7 @@ def patch_fc(x_bf16, weight, bias, drop_p: float, pre_gated_grad: bool = False, 
     if pre_gated_grad:
         h._mpo_bias_param = bias          # lets the consumer's backward write this layer's bias gradient in place
     if drop_p > 0:
-        fused = batch is not None and patch_fc_kernel_supported(x_bf16, weight)
-        h._mpo_keep_scale = 1.0 / (1.0 - (_realised_drop(drop_p) if fused else drop_p))
+        h._mpo_keep_scale = 1.0 / (1.0 - _realised_drop(drop_p))
     return h
 
 
@@ -1287,8 +1255,11 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
                                                          L.ptr(d_ctx), L.ptr(d_k), L.ptr(w_k), L.ptr(bag_data), L.ptr(d_h), gate,
                                                          L.ptr(colsum), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)),
                         "mpo_nacagat_patch_grad_fused")
-            else:                                  # the small model (E = 128): library GEMM, then the one-pass epilogue
-                d_h = torch.mm(d_k, w_k.to(torch.bfloat16))
+            else:                                  # the small model (E = 128): dK W_k on the fp32 MFMA GEMM (many-row form), then the one-pass epilogue
+                dhf = torch.empty(T, E, device=dev, dtype=torch.float32)
+                L.check(lib.mpo_linear_backward_input(L.ptr(d_k.float()), L.ptr(w_k), L.ptr(dhf), T, E, E, 1.0, 0, L.stream_of(query)),
+                        "mpo_linear_backward_input")
+                d_h = dhf.to(torch.bfloat16)
                 L.check(lib.mpo_nacagat_patch_grad(L.ptr(batch.cu), batch.n_slides, T, batch.max_rows, n_q, E, L.ptr(amap),
                                                    L.ptr(d_ctx), L.ptr(d_h), L.ptr(bag_data), L.ptr(d_h), gate, L.ptr(colsum),
                                                    batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_nacagat_patch_grad")

@@ -271,8 +271,6 @@ def test_small_model_size_matches_oracle(dev, kind, dtype):
     fwd = O.mcat_forward if kind == "mcat" else O.nacagat_forward
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     kw = dict(bag_storage=torch.bfloat16) if dtype == torch.bfloat16 else {}
-    if kw:
-        kw["round_gemm_out"] = True                       # (d = 128: the library-GEMM patch layer, not the hand-written kernel)
     hz_o, sv_o, _, _ = fwd(p, wsi, omics, **kw)
     assert float((hz.cpu() - hz_o).abs().max()) < 2e-4
     O.ces_loss(hz_o, sv_o, label, censor).backward()
@@ -300,7 +298,7 @@ def test_big_mcat_matches_oracle(dev, dtype):
     label, censor = torch.tensor([3]), torch.tensor([0.0])
     ces_loss(hz, sv, label.to(dev), censor.to(dev)).backward()
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    kw = dict(bag_storage=torch.bfloat16, round_gemm_out=True) if dtype == torch.bfloat16 else {}   # (d = 512: the library-GEMM patch layer)
+    kw = dict(bag_storage=torch.bfloat16) if dtype == torch.bfloat16 else {}   # (every width runs the one patch-layer kernel: H_bag rounded once)
     hz_o, sv_o, _, att_o = O.mcat_forward(p, wsi, omics, inference=True, **kw)
     assert float((hz.cpu() - hz_o).abs().max()) < 2e-4
     a, a_o = att["coattn"].cpu(), att_o["coattn"].detach()
@@ -340,14 +338,17 @@ def test_big_nacagat_matches_oracle(dev, dtype):
     hz_w, sv_w, _, att_w = model.forward_window(bags, om_w, inference=True)
     ces_loss(hz_w, sv_w, labels.to(dev), cens.to(dev), reduction="sum").backward()
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    kw = dict(bag_storage=torch.bfloat16, round_gemm_out=True) if dtype == torch.bfloat16 else {}   # (d = 512: the library-GEMM patch layer)
+    kw = dict(bag_storage=torch.bfloat16) if dtype == torch.bfloat16 else {}   # (every width runs the one patch-layer kernel: H_bag rounded once)
     for b, m in enumerate(lengths):
         hz_o, sv_o, _, att_o = O.nacagat_forward(p, wsis[b], omics[b], **kw)
         assert float((hz_w[b].cpu() - hz_o[0]).abs().max()) < 2e-4
         a, a_o = att_w["coattn"][b].cpu(), att_o["coattn"].detach()
         rel = ((a - a_o).abs() / a_o.clamp_min(1e-30)).max().item()
         print(f"[big nacagat] {dtype} slide {b} ({m} rows): co-attention map rel err {rel:.2e}")
-        assert rel < (1e-3 if dtype == torch.float32 else 3e-3), rel       # bf16: K comes from the bf16 bag's own rounding of H W_k^T inputs
+        # bf16: H_bag elements whose fp32 value sits near a rounding boundary land one bf16 step (2^-8 of the element) apart
+        # under the kernel's and the oracle's summation orders; K = H W_k^T carries each into the exponent (measured 3.5e-3
+        # at d = 512, printed above; the fp32 leg of this test holds the same kernels to 1e-3)
+        assert rel < (1e-3 if dtype == torch.float32 else 6e-3), rel
         O.ces_loss(hz_o, sv_o, labels[b:b + 1], cens[b:b + 1]).backward()
     for n, prm in model.named_parameters():
         ref = p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])

@@ -298,3 +298,52 @@ def test_patch_layer_alone_is_the_fused_kernel_without_its_co_attention(dev):
     gw, gb = torch.autograd.grad((h.float() * probe).sum(), [w, bias])
     (ref * probe.bfloat16().float()).sum().backward()
     assert relmax(gw, wr.grad) < 5e-3 and relmax(gb, br.grad) < 5e-3
+
+
+@pytest.mark.parametrize("embed", [128, 512])
+def test_patch_layer_widths_of_the_small_and_big_models(dev, embed):
+    """model_size 'small' / 'big' (models/mcat/mcat.py:16-21: Linear(1024, 128 | 512)) on the headline kernel: 128 = the upper
+    half of the 256-column block is zero weight rows whose stores are dropped, 512 = one pass per column half.  Values against
+    the fp32 product of the stored operands (H_bag is bf16: 2^-7 of the largest entry), the realised dropout rate and scale,
+    window == slide by slide bit for bit, gradients against autograd, and nothing written outside H_bag."""
+    lengths = [1, 127, 129, 700, 2049]
+    gen = torch.Generator().manual_seed(embed)
+    bags = [torch.randn(m, 1024, generator=gen) for m in lengths]
+    batch = BagBatch.from_list([b.to(dev).to(torch.bfloat16) for b in bags])
+    w = (torch.randn(embed, 1024, generator=gen) / 32).to(dev).requires_grad_(True)
+    bias = (torch.randn(embed, generator=gen) * 0.1).to(dev).requires_grad_(True)
+    x = batch.data.float()
+    wr, br = w.detach().bfloat16().float().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+    ref = torch.relu(x @ wr.t() + br)
+    h = ops.patch_fc(batch.data, w, bias, 0.0, batch=batch)
+    assert h.shape == (sum(lengths), embed) and h.dtype == torch.bfloat16
+    assert relmax(h.float(), ref.detach()) < 2.0 ** -7
+    for b, m in enumerate(lengths):                                     # the window's rows == the slide on its own
+        r0 = sum(lengths[:b])
+        alone = ops.patch_fc(batch.data[r0:r0 + m].contiguous(), w, bias, 0.0)
+        assert torch.equal(alone, h[r0:r0 + m])
+    probe = torch.randn_like(ref) * 0.01
+    gw, gb = torch.autograd.grad((h.float() * probe).sum(), [w, bias])
+    (ref * probe.bfloat16().float()).sum().backward()
+    assert relmax(gw, wr.grad) < 5e-3 and relmax(gb, br.grad) < 5e-3
+    # training mode: zeros where dropped, survivors scaled by 1 / (1 - realised rate); same stream -> same mask
+    ops._rng_calls = 900
+    hd = ops.patch_fc(batch.data, w, bias, 0.25, batch=batch)
+    ops._rng_calls = 900
+    hd2 = ops.patch_fc(batch.data, w, bias, 0.25, batch=batch)
+    assert torch.equal(hd, hd2)
+    pos = ref.detach() > 0.05
+    kept = (hd != 0) & pos
+    rate = 1.0 - kept.sum().item() / pos.sum().item()
+    assert abs(rate - 0.25) < 0.01, rate
+    assert abs(hd._mpo_keep_scale - 1.0 / 0.75) < 1e-12
+    assert relmax(hd.float()[kept], (ref.detach() / 0.75)[kept]) < 2.0 ** -7
+    # per-column and per-row keep rates: the counter covers every (row, 16-column group) of the wider / narrower row once
+    col_rate = 1.0 - (kept.sum(0).float() / pos.sum(0).clamp_min(1).float())
+    assert float((col_rate - 0.25).abs().max()) < 0.06, float((col_rate - 0.25).abs().max())
+
+
+def test_patch_layer_refuses_other_widths(dev):
+    x = torch.zeros(100, 1024, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="patch layer"):
+        ops.patch_fc(x, torch.zeros(384, 1024, device=dev), torch.zeros(384, device=dev), 0.0)

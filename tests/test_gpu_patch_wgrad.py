@@ -31,33 +31,51 @@ def test_patch_weight_grad_matches_fp32_product(dev, rows, patch_dim):
     assert err < 2e-6, err
 
 
-def test_patch_weight_grad_equals_the_library_split_k_product(dev):
-    gen = torch.Generator(device=dev).manual_seed(3)
-    rows = 32 * 1500
-    g = (torch.randn(rows, 256, device=dev, generator=gen) * 0.01).to(torch.bfloat16)
-    x = torch.randn(rows, 1024, device=dev, generator=gen).to(torch.bfloat16)
-    a, b = torch.empty(256, 1024, device=dev), torch.empty(256, 1024, device=dev)
-    ops.patch_weight_grad(g, x, a)
-    ops._splitk_tn(g, x, b)
-    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
-
-
-def test_unsupported_shapes_take_the_library_path(dev):
-    g = torch.randn(500, 128, device=dev).to(torch.bfloat16)           # embed 128 ('small'): not built, library product
-    x = torch.randn(500, 1024, device=dev).to(torch.bfloat16)
-    out = torch.empty(128, 1024, device=dev)
-    ops.patch_weight_grad(g, x, out)
-    torch.testing.assert_close(out.double(), _ref(g, x), rtol=1e-4, atol=1e-4)
-
-
-@pytest.mark.parametrize("patch_dim", [768, 1280])
-def test_patch_dims_the_launcher_refuses_take_the_library_path(dev, patch_dim):
-    """embed 256 but a patch width the kernel's 256-row-range split does not divide (the launcher wants 256 % (k / 256) == 0):
-    the Python gate must route these to the library product instead of raising in backward."""
-    gen = torch.Generator(device=dev).manual_seed(patch_dim)
-    g = (torch.randn(3000, 256, device=dev, generator=gen) * 0.1).to(torch.bfloat16)
-    x = torch.randn(3000, patch_dim, device=dev, generator=gen).to(torch.bfloat16)
-    out = torch.empty(256, patch_dim, device=dev)
+@pytest.mark.parametrize("embed,patch_dim", [(128, 1024), (512, 1024), (128, 128), (512, 512)])
+@pytest.mark.parametrize("rows", [1, 33, 2049, 48001])
+def test_small_and_big_embed_widths(dev, embed, patch_dim, rows):
+    """model_size 'small' (embed 128: the g image's upper half repeats the lower, those rows of dW are not written) and
+    'big' (512: one pass per 256 columns of g, row pitch 1024 B) on the same kernel (models/mcat/mcat.py:16-21); the square
+    cases are NaCAGaT's key-projection weight gradient d_k^T H_bag at those sizes (models/nacagat/nacagat.py:17-18)."""
+    gen = torch.Generator(device=dev).manual_seed(rows + embed)
+    gbuf = torch.full((rows + 64, embed), float("nan"), device=dev, dtype=torch.bfloat16)
+    xbuf = torch.full((rows + 64, patch_dim), float("nan"), device=dev, dtype=torch.bfloat16)
+    g, x = gbuf[:rows], xbuf[:rows]
+    g.copy_(torch.randn(rows, embed, device=dev, generator=gen) * (torch.rand(rows, embed, device=dev, generator=gen) > 0.3))
+    x.copy_(torch.randn(rows, patch_dim, device=dev, generator=gen))
+    guard = torch.full((embed + 8, patch_dim), float("nan"), device=dev)
+    out = guard[:embed]
     ops.patch_weight_grad(g, x, out)
     ref = _ref(g, x)
-    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-4
+    err = float((out.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    assert err < 2e-6, err
+    assert torch.isnan(guard[embed:]).all()                 # nothing written past dW's rows
+
+
+def test_a_patch_matrix_of_more_than_4_gib_goes_in_row_segments(dev):
+    """The kernel's DMA offsets are 32-bit: 2 200 000 x 1024 bf16 rows (4.5 GB) are two launches whose second accumulates."""
+    rows = 2_200_000
+    gen = torch.Generator(device=dev).manual_seed(9)
+    x = torch.empty(rows, 1024, device=dev, dtype=torch.bfloat16)
+    g = torch.empty(rows, 256, device=dev, dtype=torch.bfloat16)
+    for r0 in range(0, rows, 200_000):                      # (filled in pieces: no multi-GB fp32 temporaries)
+        r1 = min(rows, r0 + 200_000)
+        x[r0:r1] = torch.randn(r1 - r0, 1024, device=dev, generator=gen)
+        g[r0:r1] = torch.randn(r1 - r0, 256, device=dev, generator=gen) * 0.05
+    out = torch.full((256, 1024), float("nan"), device=dev)
+    ops.patch_weight_grad(g, x, out)
+    ref = torch.zeros(256, 1024, device=dev, dtype=torch.float64)
+    for r0 in range(0, rows, 100_000):
+        r1 = min(rows, r0 + 100_000)
+        ref += g[r0:r1].double().t() @ x[r0:r1].double()
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err
+
+
+@pytest.mark.parametrize("embed,patch_dim", [(256, 768), (256, 1280), (64, 1024)])
+def test_geometries_the_kernel_is_not_built_for_raise(dev, embed, patch_dim):
+    """One code path: no library product behind the kernel -- a width it does not cover is an error, not a slow detour."""
+    g = torch.zeros(3000, embed, device=dev, dtype=torch.bfloat16)
+    x = torch.zeros(3000, patch_dim, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="patch weight gradient"):
+        ops.patch_weight_grad(g, x, torch.empty(embed, patch_dim, device=dev))
