@@ -38,6 +38,8 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="mcat", choices=["mcat", "nacagat"])
+    ap.add_argument("--model-size", default="medium", choices=["small", "medium", "big"],
+                    help="models/mcat/mcat.py:16-21; the headline (and the default) is medium = embed 256")
     ap.add_argument("--window", type=int, default=32, help="slides per rank per optimiser step (grad_acc_step)")
     ap.add_argument("--patches", type=int, default=15000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -82,7 +84,7 @@ def self_launch(a, argv):
 
 
 # ------------------------------------------------------------------------------------------------ workload
-def build_model(kind, dev, bag_dtype, rank):
+def build_model(kind, dev, bag_dtype, rank, size="medium"):
     """Weights: module default init under torch.manual_seed(0) on EVERY rank (replicas start identical; FlatAdam's flat
     parameter buffer is additionally broadcast from rank 0).  Afterwards the generator is re-seeded per rank: the Philox
     seed of every dropout stream is torch.initial_seed() (ops._reserve), so ranks draw different masks."""
@@ -91,7 +93,7 @@ def build_model(kind, dev, bag_dtype, rank):
                                                  NarrowContextualAttentionGateTransformer)
     torch.manual_seed(0)
     cls = MultimodalCoAttentionTransformer if kind == "mcat" else NarrowContextualAttentionGateTransformer
-    model = cls(omic_sizes=[256] * 6, model_size="medium", bag_dtype=bag_dtype).to(dev).train()
+    model = cls(omic_sizes=[256] * 6, model_size=size, bag_dtype=bag_dtype).to(dev).train()
     torch.manual_seed(BASE_SEED + 1000 * (rank + 1))
     return model
 
@@ -354,7 +356,7 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
     from multimodal_path_omic_amd.dp import FlatAdam, FlatGradBucket
     from multimodal_path_omic_amd.harness import GraphedWindowStep, train_window
     bag_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = build_model(a.model, dev, bag_dtype, rank)
+    model = build_model(a.model, dev, bag_dtype, rank, a.model_size)
     bucket = FlatGradBucket(list(model.parameters()))
     opt = FlatAdam(bucket, lr=2e-4, weight_decay=1e-5)            # adam, lr 2e-4, wd 1e-5: config.yaml:57-63
     if world > 1:
@@ -436,7 +438,7 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
             "metric": "slides/sec (fwd+bwd) at 15k-patch bags", "value": round(slides / dt, 2), "unit": "slides/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if getattr(a, "strong", False) else "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"{a.model.upper()} medium whole model fwd+bwd+Adam, "
+            "config": {"workload": f"{a.model.upper()} {a.model_size} whole model fwd+bwd+Adam, "
                                    f"{'2k-30k' if a.ragged else a.patches}x1024 {a.dtype} patch bag "
                                    f"+ 6x256 omic tokens per slide, ces loss", "slides_per_rank_per_step": a.window,
                        "global_slides_per_step": world * a.window,
