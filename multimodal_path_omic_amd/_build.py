@@ -21,6 +21,12 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          "-Rpass-analysis=kernel-resource-usage"]      # per-kernel registers / scratch / LDS -> <obj>.usage.json
 
 
+# Per-file additions.  bag_selfattn.hip: its kernels are vector-ALU bound (softmax arithmetic per score element beside the
+# MFMAs); left to its default the compiler parks MFMA results in AGPRs and spends 10-28 % of the vector instructions of
+# every loop trip on v_accvgpr_read / _write copies.  None of these kernels needs the second register file.
+FILE_FLAGS = {"bag_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -60,7 +66,7 @@ def _compile(src):
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _headers_mtime()):
         return obj, None
-    cmd = ["hipcc", *FLAGS, "-c", path, "-o", obj]
+    cmd = ["hipcc", *FLAGS, *FILE_FLAGS.get(src, []), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")

@@ -620,6 +620,33 @@ __device__ __forceinline__ void b3_split8(const f32x4& a, const f32x4& b, bf16x8
         split_bf16(b[e], h, l); hi[4 + e] = h; lo[4 + e] = l;
     }
 }
+// The same split, pair by pair: one packed conversion for the two high parts, their fp32 values back by a shift and a mask, one
+// packed subtraction, one packed conversion for the two low parts (5 vector instructions per two elements; element by element the
+// compiler spends 6-7).  These kernels are bound by the vector ALU: every instruction per score element counts.
+typedef __attribute__((ext_vector_type(2))) float f32x2_sa;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_sa;
+__device__ __forceinline__ void b3_split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_sa{a, b}, bf16x2_sa));
+    const f32x2_sa hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xFFFF0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_sa{a, b} - hf, bf16x2_sa));
+}
+__device__ __forceinline__ void b3_split8p(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_sa;
+    uint32_t h[4], l[4];
+    b3_split_pair(a[0], a[1], h[0], l[0]);
+    b3_split_pair(a[2], a[3], h[1], l[1]);
+    b3_split_pair(b[0], b[1], h[2], l[2]);
+    b3_split_pair(b[2], b[3], h[3], l[3]);
+    hi = __builtin_bit_cast(bf16x8, u32x4_sa{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(bf16x8, u32x4_sa{l[0], l[1], l[2], l[3]});
+}
+// keep ? v : 0 for the four elements of a lane's row group (bytes of the lane's mask word): a byte compare and a select each
+__device__ __forceinline__ f32x4 b3_keep4(const SaDrop& d, uint32_t word, const f32x4& v) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = ((word >> (8 * r)) & 255u) >= d.thr ? v[r] : 0.f;
+    return o;
+}
 // forward / dQ orientation (lane column = query q, NT key tiles): w[t] = word (q % 4) of the block of (q / 4, tile t's keys) --
 // the one word of each block this lane's query uses, hashed directly (two multiplies per tile; no exchange between lanes)
 template <int NT>
@@ -688,8 +715,9 @@ void sa_b3_split_kernel(const float* __restrict__ src, int ld, int col0, int M, 
     }
 }
 
-// grid (Mp / 64, heads, sequences); Q, K in row form, V in T form
-template <int HD>
+// grid (Mp / 64, heads, sequences); Q, K in row form, V in T form.  DROP: attention dropout on (a template parameter, not a
+// uniform branch: a branch around each tile's select makes the compiler copy the whole score block at every join)
+template <int HD, bool DROP>
 __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, float* __restrict__ lse2, int M, int Mp, int d, float scale,
                           float drop_p, unsigned long long seed, unsigned long long offset, const unsigned long long* epoch) {
@@ -709,7 +737,8 @@ void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, f
     f32x4 acc[C::CT];
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY;
+    f32x2_sa l2 = {0.f, 0.f};                                // row sum (before dropout) in two halves: packed adds
     uint4 s_kh[B3Stage<HD>::RV], s_kl[B3Stage<HD>::RV], s_vh[B3Stage<HD>::TV], s_vl[B3Stage<HD>::TV];
     auto stage = [&](int n0) __attribute__((always_inline)) {
         b3_stage_rows<HD>(s_kh, K.rh + hoff + (size_t)n0 * HD);
@@ -734,47 +763,53 @@ void bag_sa_b3_fwd_kernel(B3Form Q, B3Form K, B3Form V, float* __restrict__ o, f
             if (C::kDma) b3_dma_wait();
         }
         __syncthreads();
+        // Per score element: its share of the row maximum (max3 over raw products), ONE packed fma + exp2 (the scale and the
+        // maximum go in together: p = exp2(c2 dot - mx)), a packed add into the row sum, the dropout select (its keep-scale is
+        // applied once, to the output), the hi / lo split of the second product's operand.
         f32x4 s[C::NT];
-        float mx = m;
         const bool edge = n0 + C::BN > M;                    // uniform: only the last step has keys past the end
+        float rmx = -INFINITY;                               // maximum of the RAW products of the step (c2 > 0)
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
-            s[t] = b3_dot<HD>(kh, kl, t, qh, ql, j, kk) * c2;
+            s[t] = b3_dot<HD>(kh, kl, t, qh, ql, j, kk);
             if (edge) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[t][r] = (n0 + 16 * t + 4 * kk + r < M) ? s[t][r] : -INFINITY;
             }
-            mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+            rmx = fmaxf(fmaxf(rmx, s[t][0]), s[t][1]);
+            rmx = fmaxf(fmaxf(rmx, s[t][2]), s[t][3]);
         }
+        float mx = fmaxf(m, rmx * c2);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float alpha = fast_exp2(m - mx);
         m = mx;
-        l *= alpha;
+        l2 *= alpha;
 #pragma unroll
         for (int c = 0; c < C::CT; ++c) acc[c] *= alpha;
         uint32_t w[C::NT];
-        if (dr.thr) b3_words_q<C::NT>(dr, q, n0, kk, lane, w);
+        if constexpr (DROP) b3_words_q<C::NT>(dr, q, n0, kk, lane, w);
+        const f32x2_sa c2v = {c2, c2}, nmx = {-mx, -mx};
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[t][r] = fast_exp2(s[t][r] - mx); l += s[t][r]; }
-            if (dr.thr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] *= sa_keep(dr, w[t], r);
-            }
+            const f32x2_sa a0 = f32x2_sa{s[t][0], s[t][1]} * c2v + nmx, a1 = f32x2_sa{s[t][2], s[t][3]} * c2v + nmx;
+            s[t] = f32x4{fast_exp2(a0[0]), fast_exp2(a0[1]), fast_exp2(a1[0]), fast_exp2(a1[1])};
+            l2 += f32x2_sa{s[t][0], s[t][1]};
+            l2 += f32x2_sa{s[t][2], s[t][3]};
+            if constexpr (DROP) s[t] = b3_keep4(dr, w[t], s[t]);
         }
 #pragma unroll
         for (int g = 0; g < C::NG; ++g) {
             bf16x8 ph, pl;
-            b3_split8(s[2 * g], s[2 * g + 1], ph, pl);
+            b3_split8p(s[2 * g], s[2 * g + 1], ph, pl);
             b3_tacc<HD>(acc, vh, vl, g, ph, pl, j, kk);
         }
     }
+    float l = l2[0] + l2[1];
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     if (q < M) {
-        const float inv = 1.0f / l;
+        const float inv = dr.inv_keep / l;                   // (the kept probabilities were accumulated unscaled)
 #pragma unroll
         for (int c = 0; c < C::CT; ++c)
             *reinterpret_cast<float4*>(o + (size_t)q * d + h * HD + 16 * c + 4 * kk) =
@@ -842,7 +877,7 @@ void bag_sa_b3_map_kernel(B3Form Q, B3Form K, const float* __restrict__ lse2, fl
 }
 
 // dQ (+ delta): Q, dO row form (the wave's own rows); K, V row form and K T form streamed
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_b3_dq_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* __restrict__ o, const float* __restrict__ d_o,
                          const float* __restrict__ lse2, float* __restrict__ dqkv, float* __restrict__ delta, int M, int Mp, int d,
@@ -912,28 +947,35 @@ void bag_sa_b3_dq_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* _
         }
         __syncthreads();
         uint32_t w[C::NT];
-        if (dr.thr) b3_words_q<C::NT>(dr, q, n0, kk, lane, w);
+        if constexpr (DROP) b3_words_q<C::NT>(dr, q, n0, kk, lane, w);
         const bool edge = n0 + C::BN > M;
         f32x4 ds[C::NT];
+        // per element: p = exp2(c2 s - lse) (packed fma), dS = p (keep ? dP / (1 - p_drop) - delta : -delta) (packed fma, byte
+        // compare + select, packed multiply), the pairwise hi / lo split
+        const f32x2_sa c2v = {c2, c2}, nls = {-ls, -ls}, ikv = {dr.inv_keep, dr.inv_keep}, ndl = {-dl, -dl};
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
             const f32x4 s = b3_dot<HD>(kh, kl, t, qh, ql, j, kk);
-            f32x4 dp = b3_dot<HD>(vh, vl, t, doh, dol, j, kk);
-            if (dr.thr) {
+            const f32x4 dp = b3_dot<HD>(vh, vl, t, doh, dol, j, kk);
+            const f32x2_sa a0 = f32x2_sa{s[0], s[1]} * c2v + nls, a1 = f32x2_sa{s[2], s[3]} * c2v + nls;
+            f32x4 p = {fast_exp2(a0[0]), fast_exp2(a0[1]), fast_exp2(a1[0]), fast_exp2(a1[1])};
+            if (edge) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dp[r] *= sa_keep(dr, w[t], r);
+                for (int r = 0; r < 4; ++r) p[r] = (n0 + 16 * t + 4 * kk + r < M) ? p[r] : 0.f;
             }
+            const f32x2_sa u0 = f32x2_sa{dp[0], dp[1]} * ikv + ndl, u1 = f32x2_sa{dp[2], dp[3]} * ikv + ndl;
+            f32x4 u = {u0[0], u0[1], u1[0], u1[1]};
+            if constexpr (DROP) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = fast_exp2(s[r] * c2 - ls);
-                if (edge) p = (n0 + 16 * t + 4 * kk + r < M) ? p : 0.f;
-                ds[t][r] = p * (dp[r] - dl);
+                for (int r = 0; r < 4; ++r) u[r] = ((w[t] >> (8 * r)) & 255u) >= dr.thr ? u[r] : -dl;
             }
+            const f32x2_sa d0 = f32x2_sa{p[0], p[1]} * f32x2_sa{u[0], u[1]}, d1 = f32x2_sa{p[2], p[3]} * f32x2_sa{u[2], u[3]};
+            ds[t] = f32x4{d0[0], d0[1], d1[0], d1[1]};
         }
 #pragma unroll
         for (int g = 0; g < C::NG; ++g) {
             bf16x8 dh, dlo;
-            b3_split8(ds[2 * g], ds[2 * g + 1], dh, dlo);
+            b3_split8p(ds[2 * g], ds[2 * g + 1], dh, dlo);
             b3_tacc<HD>(acc, kth, ktl, g, dh, dlo, j, kk);
         }
     }
@@ -946,7 +988,7 @@ void bag_sa_b3_dq_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* _
 }
 
 // dK, dV: K, V row form (the wave's own rows); Q, dO row and T forms streamed
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(64 * kSaWaves)
 void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* __restrict__ lse2, const float* __restrict__ delta,
                           float* __restrict__ dqkv, int M, int Mp, int d, float scale, float drop_p, unsigned long long seed,
@@ -1015,28 +1057,39 @@ void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* 
         }
         __syncthreads();
         uint32_t w[C::NT][4];
-        if (dr.thr) b3_blocks_key<C::NT>(dr, key, q0, kk, lane, w);
+        if constexpr (DROP) b3_blocks_key<C::NT>(dr, key, q0, kk, lane, w);
         f32x4 pd[C::NT], ds[C::NT];
+        // per element: p = exp2(c2 s - lse_q) (packed fma; rows past the end carry lse = +inf: p = 0), the kept probability for
+        // dV (its keep-scale is applied once, to the result), dS = p (keep ? dP / (1 - p_drop) - delta_q : -delta_q), the splits
+        const f32x2_sa c2v = {c2, c2}, ikv = {dr.inv_keep, dr.inv_keep};
+        const int ksh = 8 * (key & 3);                       // this lane's byte of a block word
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
             const f32x4 s = b3_dot<HD>(qh, ql, t, kh, kl, j, kk);
             const f32x4 dp = b3_dot<HD>(gh, gl, t, vh, vl, j, kk);
-            const float4 ls = *reinterpret_cast<const float4*>(ls_t + 16 * t + 4 * kk);
-            const float4 dl = *reinterpret_cast<const float4*>(dl_t + 16 * t + 4 * kk);
-            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(ls_t + 16 * t + 4 * kk);
+            const f32x4 dl = *reinterpret_cast<const f32x4*>(dl_t + 16 * t + 4 * kk);
+            const f32x2_sa a0 = f32x2_sa{s[0], s[1]} * c2v - f32x2_sa{ls[0], ls[1]}, a1 = f32x2_sa{s[2], s[3]} * c2v - f32x2_sa{ls[2], ls[3]};
+            const f32x4 p = {fast_exp2(a0[0]), fast_exp2(a0[1]), fast_exp2(a1[0]), fast_exp2(a1[1])};
+            const f32x2_sa u0 = f32x2_sa{dp[0], dp[1]} * ikv - f32x2_sa{dl[0], dl[1]}, u1 = f32x2_sa{dp[2], dp[3]} * ikv - f32x2_sa{dl[2], dl[3]};
+            f32x4 u = {u0[0], u0[1], u1[0], u1[1]};
+            pd[t] = p;
+            if constexpr (DROP) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(s[r] * c2 - lsv[r]);
-                const float keep = dr.thr ? sa_keep(dr, w[t][r], key & 3) : 1.0f;
-                pd[t][r] = p * keep;
-                ds[t][r] = p * (dp[r] * keep - dlv[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const bool kept = ((w[t][r] >> ksh) & 255u) >= dr.thr;
+                    pd[t][r] = kept ? p[r] : 0.f;
+                    u[r] = kept ? u[r] : -dl[r];
+                }
             }
+            const f32x2_sa d0 = f32x2_sa{p[0], p[1]} * f32x2_sa{u[0], u[1]}, d1 = f32x2_sa{p[2], p[3]} * f32x2_sa{u[2], u[3]};
+            ds[t] = f32x4{d0[0], d0[1], d1[0], d1[1]};
         }
 #pragma unroll
         for (int g = 0; g < C::NG; ++g) {
             bf16x8 ph, pl, sh_, sl_;
-            b3_split8(pd[2 * g], pd[2 * g + 1], ph, pl);
-            b3_split8(ds[2 * g], ds[2 * g + 1], sh_, sl_);
+            b3_split8p(pd[2 * g], pd[2 * g + 1], ph, pl);
+            b3_split8p(ds[2 * g], ds[2 * g + 1], sh_, sl_);
             b3_tacc<HD>(dv, gth, gtl, g, ph, pl, j, kk);
             b3_tacc<HD>(dk, qth, qtl, g, sh_, sl_, j, kk);
         }
@@ -1046,7 +1099,8 @@ void bag_sa_b3_dkv_kernel(B3Form Q, B3Form K, B3Form V, B3Form DO, const float* 
         for (int c = 0; c < C::CT; ++c) {
             float* at = dqkv + (size_t)key * 3 * d + h * HD + 16 * c + 4 * kk;
             *reinterpret_cast<float4*>(at + d) = make_float4(dk[c][0] * scale, dk[c][1] * scale, dk[c][2] * scale, dk[c][3] * scale);
-            *reinterpret_cast<float4*>(at + 2 * d) = make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]);
+            const float ik = dr.inv_keep;                    // (the kept probabilities were accumulated unscaled)
+            *reinterpret_cast<float4*>(at + 2 * d) = make_float4(dv[c][0] * ik, dv[c][1] * ik, dv[c][2] * ik, dv[c][3] * ik);
         }
     }
 }
@@ -1081,7 +1135,10 @@ int b3_forward(const float* qkv, int n_seq, int M, int d, int H, float drop_p, u
     if (int rc = b3_split<HD>(qkv, 3 * d, d, n_seq, M, H, K, true, true, s)) return rc;
     if (int rc = b3_split<HD>(qkv, 3 * d, 2 * d, n_seq, M, H, V, true, true, s)) return rc;
     const float scale = 1.0f / sqrtf((float)HD);
-    bag_sa_b3_fwd_kernel<HD><<<dim3(Mp / 64, H, n_seq), 64 * kSaWaves, 0, s>>>(Q, K, V, o, saved, M, Mp, d, scale, drop_p, seed, offset, epoch);
+    if (drop_p > 0.f && (unsigned)(drop_p * 256.0f + 0.5f) > 0u)
+        bag_sa_b3_fwd_kernel<HD, true><<<dim3(Mp / 64, H, n_seq), 64 * kSaWaves, 0, s>>>(Q, K, V, o, saved, M, Mp, d, scale, drop_p, seed, offset, epoch);
+    else
+        bag_sa_b3_fwd_kernel<HD, false><<<dim3(Mp / 64, H, n_seq), 64 * kSaWaves, 0, s>>>(Q, K, V, o, saved, M, Mp, d, scale, 0.f, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     if (map) {
         const int qb = Mp / 64, nblk = (M + B3Cfg<HD>::BN - 1) / B3Cfg<HD>::BN;
@@ -1103,9 +1160,16 @@ int b3_backward(const float* o, const float* saved, const float* d_o, int n_seq,
     if (int rc = b3_split<HD>(d_o, d, 0, n_seq, M, H, DO, true, true, s)) return rc;
     const float scale = 1.0f / sqrtf((float)HD);
     const dim3 grid(Mp / 64, H, n_seq);
-    bag_sa_b3_dq_kernel<HD><<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, o, d_o, saved, dqkv, scratch, M, Mp, d, scale, drop_p, seed, offset, epoch);
+    const bool drop_on = drop_p > 0.f && (unsigned)(drop_p * 256.0f + 0.5f) > 0u;
+    if (drop_on)
+        bag_sa_b3_dq_kernel<HD, true><<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, o, d_o, saved, dqkv, scratch, M, Mp, d, scale, drop_p, seed, offset, epoch);
+    else
+        bag_sa_b3_dq_kernel<HD, false><<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, o, d_o, saved, dqkv, scratch, M, Mp, d, scale, 0.f, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
-    bag_sa_b3_dkv_kernel<HD><<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, saved, scratch, dqkv, M, Mp, d, scale, drop_p, seed, offset, epoch);
+    if (drop_on)
+        bag_sa_b3_dkv_kernel<HD, true><<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, saved, scratch, dqkv, M, Mp, d, scale, drop_p, seed, offset, epoch);
+    else
+        bag_sa_b3_dkv_kernel<HD, false><<<grid, 64 * kSaWaves, 0, s>>>(Q, K, V, DO, saved, scratch, dqkv, M, Mp, d, scale, 0.f, seed, offset, epoch);
     MPO_LAUNCH_CHECK();
     return 0;
 }

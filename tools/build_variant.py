@@ -19,7 +19,7 @@ flags = [f for f in B.FLAGS if not f.startswith("-Rpass")] + extra
 
 def comp(src):
     obj = os.path.join(objdir, src[:-4] + ".o")
-    r = subprocess.run(["hipcc", *flags, "-c", os.path.join(B.CSRC, src), "-o", obj], capture_output=True, text=True)
+    r = subprocess.run(["hipcc", *flags, *B.FILE_FLAGS.get(src, []), "-c", os.path.join(B.CSRC, src), "-o", obj], capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(r.stderr[-3000:])
     return obj
