@@ -546,7 +546,7 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
     if (mpo_coattn_bwd8_covers(bag_f32, embed, n_q, da_map))
         return mpo_launch_coattn_bwd8(bag, cu, qk2, lse2, dctx, delta, ctx, dbag, part_dqk, part_colsum, n_q, plan, relu_gate, stream);
     if (mpo_coattn_bwd_f32_covers(bag_f32, embed, n_q, da_map))
-        return mpo_launch_coattn_bwd_f32(bag, cu, qk2, lse2, dctx, delta, ctx, dbag, part_dqk, part_colsum, n_q, plan, stream);
+        return mpo_launch_coattn_bwd_f32(bag, cu, qk2, lse2, dctx, delta, ctx, da_map, dbag, part_dqk, part_colsum, n_q, plan, stream);
     dim3 grid = plan_grid(plan);
 #define MPO_BWD_CASE(EV)                                                                                     \
     case EV:                                                                                                 \

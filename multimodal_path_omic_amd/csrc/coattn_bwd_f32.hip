@@ -1,6 +1,7 @@
 // K1 backward for an fp32-stored bag (the reference's own storage; BASELINE configuration 5: 100 000-patch fp32 slides),
-// embed 256, N <= 8 queries, no gradient on the map: the arithmetic of coattn_bwd.hip
-//   S[n][m] = qk[n].H[m],  A = exp2(S - lse),  dA[n][m] = dctx[n].H[m],  dS = A (dA - delta),
+// embed 256, N <= 8 queries, with or without a gradient arriving on the map (the `cesar` loss's ||A||_2 term,
+// models/loss.py:88-101): the arithmetic of coattn_bwd.hip
+//   S[n][m] = qk[n].H[m],  A = exp2(S - lse),  dA[n][m] = dctx[n].H[m] (+ da_map[n][m]),  dS = A (dA - delta),
 //   dqk[n] = sum_m dS[n][m] H[m],   dH[m] = sum_n A[n][m] dctx[n] + dS[n][m] qk[n]
 // on the VECTOR ALUs in plain fp32 (models/mcat/mcat.py:97 differentiated; the forward is coattn_fwd.hip).
 //
@@ -14,6 +15,8 @@
 // columns of qk / dctx held in registers.  No LDS image, no fragments, no
 // splitting: plain fp32 products (the MFMA path carries the split's 2^-17).  8 waves per workgroup; the rows of the next
 // 16-row step are requested into the register a row has just left (bag_key_grad_kernel's ring).
+#include <type_traits>
+
 #include "coattn_tile.h"
 #include "mpo_common.h"
 #include "mpo_kernels.h"
@@ -55,7 +58,16 @@ __device__ __forceinline__ float row_allsum(float v) {
     return v;
 }
 
-template <int NQA>
+// lane I of every 16-lane row to all lanes of its row (DPP row_newbcast: one vector instruction)
+template <int I>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + I, 0xF, 0xF, false));
+}
+
+// DMAP: a gradient arrives on the map (da_map, ragged [n_q][M_b] per slide; delta then already holds rowsum(A da_map) too).
+// Its values enter on the FOLDED registers (one lane row per query): a step's 16 rows x (up to) 8 queries are fetched as two
+// coalesced loads -- lane (16 row-of-queries + i) takes (query, row i) -- and row i's are broadcast along the lane rows.
+template <int NQA, bool DMAP>
 __global__ __launch_bounds__(F_WAVES * 64, 1)
 void coattn_bwd_f32_kernel(const float* __restrict__ bag, const int* __restrict__ cu,
                            const float* __restrict__ qk2,      // [n_slides][n_q][256] log2 units
@@ -63,6 +75,7 @@ void coattn_bwd_f32_kernel(const float* __restrict__ bag, const int* __restrict_
                            const float* __restrict__ dctx,     // [n_slides][n_q][256]
                            const float* __restrict__ delta,    // [n_slides][n_q] or NULL: rowsum(dctx * ctx) computed here
                            const float* __restrict__ ctx,      // [n_slides][n_q][256], read when delta == NULL
+                           const float* __restrict__ da_map,   // DMAP: ragged [n_q][M_b] per slide
                            float* __restrict__ dbag,           // [total_rows][256]
                            float* __restrict__ part_dqk,       // [parts][n_q][256] (natural units)
                            float* __restrict__ part_colsum,    // nullable [parts][256]
@@ -125,7 +138,9 @@ void coattn_bwd_f32_kernel(const float* __restrict__ bag, const int* __restrict_
     // 16-lane row), then four DPP steps finish all four at once -- 10 swaps + 16 DPP adds per row for 12..16 values instead
     // of 8 operations per value; exp2 and dS run on the folded registers (one lane row per query), and the 2 N scalars
     // every lane needs come back as v_readlane broadcasts.
-    auto row_math = [&](const f32x4& h, f32x4& o) {
+    const float* da_b = DMAP ? da_map + (size_t)n_q * wg.row_begin : nullptr;
+    const bool lo_live = fq < n_q, hi_live = NQA > 4 && 4 + fq < n_q;
+    auto row_math = [&](const f32x4& h, f32x4& o, float dm_lo, float dm_hi) {
         float sp[8], dp[8];
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
@@ -140,13 +155,15 @@ void coattn_bwd_f32_kernel(const float* __restrict__ bag, const int* __restrict_
             }
         }
         const float s_lo = row_allsum(fold16(fold32(sp[0], sp[1]), fold32(sp[2], sp[3])));   // rows: queries 0, 2, 1, 3
-        const float d_lo = row_allsum(fold16(fold32(dp[0], dp[1]), fold32(dp[2], dp[3])));
+        float d_lo = row_allsum(fold16(fold32(dp[0], dp[1]), fold32(dp[2], dp[3])));
+        if constexpr (DMAP) d_lo += dm_lo;
         const float a_lo = __builtin_amdgcn_exp2f(s_lo - ls_lo);
         const float ds_lo = a_lo * (d_lo - dl_lo);
         float a_hi = 0.f, ds_hi = 0.f;
         if constexpr (NQA > 4) {
             const float s_hi = row_allsum(fold16(fold32(sp[4], sp[5]), fold32(sp[6], sp[7])));   // rows: queries 4, 6, 5, 7
-            const float d_hi = row_allsum(fold16(fold32(dp[4], dp[5]), fold32(dp[6], dp[7])));
+            float d_hi = row_allsum(fold16(fold32(dp[4], dp[5]), fold32(dp[6], dp[7])));
+            if constexpr (DMAP) d_hi += dm_hi;
             a_hi = __builtin_amdgcn_exp2f(s_hi - ls_hi);
             ds_hi = a_hi * (d_hi - dl_hi);
         }
@@ -163,16 +180,27 @@ void coattn_bwd_f32_kernel(const float* __restrict__ bag, const int* __restrict_
     };
     auto step = [&](int st) {                                    // all 16 rows exist: nothing is predicated
         const int row0 = step_row(st);
-#pragma unroll
-        for (int i = 0; i < F_HR; ++i) {
+        float dmv_lo = 0.f, dmv_hi = 0.f;                         // DMAP: (this lane row's query, row row0 + (lane & 15))
+        if constexpr (DMAP) {
+            if (lo_live) dmv_lo = da_b[(size_t)fq * m_rows + row0 + (lane & 15)];
+            if (hi_live) dmv_hi = da_b[(size_t)(4 + fq) * m_rows + row0 + (lane & 15)];
+        }
+        auto one = [&](auto tag) {
+            constexpr int i = decltype(tag)::value;
             const f32x4 h = hv[i];
             fetch_row(st + 1, i);                                 // the register is free again: next step's row i
             f32x4 o;
-            row_math(h, o);
+            row_math(h, o, DMAP ? row_bcast<i>(dmv_lo) : 0.f, DMAP ? row_bcast<i>(dmv_hi) : 0.f);
             *reinterpret_cast<f32x4*>(dslide + (size_t)(row0 + i) * F_E + 4 * lane) = o;
             csum += o;
             __builtin_amdgcn_sched_barrier(0);                    // one row's working set at a time
-        }
+        };
+        using std::integral_constant;
+        one(integral_constant<int, 0>{}); one(integral_constant<int, 1>{}); one(integral_constant<int, 2>{}); one(integral_constant<int, 3>{});
+        one(integral_constant<int, 4>{}); one(integral_constant<int, 5>{}); one(integral_constant<int, 6>{}); one(integral_constant<int, 7>{});
+        one(integral_constant<int, 8>{}); one(integral_constant<int, 9>{}); one(integral_constant<int, 10>{}); one(integral_constant<int, 11>{});
+        one(integral_constant<int, 12>{}); one(integral_constant<int, 13>{}); one(integral_constant<int, 14>{}); one(integral_constant<int, 15>{});
+        static_assert(F_HR == 16, "one() per row of a step");
     };
     auto ragged_step = [&](int st) {                             // the last step(s) of a range: the rows that exist, loaded where used
         const int row0 = step_row(st);
@@ -180,7 +208,12 @@ void coattn_bwd_f32_kernel(const float* __restrict__ bag, const int* __restrict_
         for (int i = 0; i < nvalid; ++i) {
             const f32x4 h = *reinterpret_cast<const f32x4*>(slide + (size_t)(row0 + i) * F_E + 4 * lane);
             f32x4 o;
-            row_math(h, o);
+            float dm_lo = 0.f, dm_hi = 0.f;
+            if constexpr (DMAP) {                                 // (every lane of a lane row reads the same value)
+                if (lo_live) dm_lo = da_b[(size_t)fq * m_rows + row0 + i];
+                if (hi_live) dm_hi = da_b[(size_t)(4 + fq) * m_rows + row0 + i];
+            }
+            row_math(h, o, dm_lo, dm_hi);
             *reinterpret_cast<f32x4*>(dslide + (size_t)(row0 + i) * F_E + 4 * lane) = o;
             csum += o;
         }
@@ -225,24 +258,25 @@ int mpo_coattn_bwd_f32_enable(int enabled) {
     return was;
 }
 bool mpo_coattn_bwd_f32_covers(int bag_f32, int embed, int n_q, const float* da_map) {
-    return g_bwd_f32_enabled && bag_f32 && embed == F_E && n_q >= 1 && n_q <= 8 && da_map == nullptr;
+    (void)da_map;                                             // (with or without a gradient on the map)
+    return g_bwd_f32_enabled && bag_f32 && embed == F_E && n_q >= 1 && n_q <= 8;
 }
 
 int mpo_launch_coattn_bwd_f32(const void* bag, const int* cu, const float* qk2, const float* lse2, const float* dctx,
-                              const float* delta, const float* ctx, void* dbag, float* part_dqk, float* part_colsum, int n_q,
-                              const BagPlan& plan, hipStream_t stream) {
+                              const float* delta, const float* ctx, const float* da_map, void* dbag, float* part_dqk,
+                              float* part_colsum, int n_q, const BagPlan& plan, hipStream_t stream) {
     MPO_CHECK(n_q >= 1 && n_q <= 8, "coattn backward (fp32 bag): 1..8 queries (got %d)", n_q);
     MPO_CHECK(delta || ctx, "coattn backward: delta or ctx");
+    MPO_CHECK(da_map == nullptr || delta != nullptr, "coattn backward (fp32 bag): a gradient on the map needs delta (with its share in)");
     MPO_CHECK(((reinterpret_cast<uintptr_t>(bag) | reinterpret_cast<uintptr_t>(dbag) | reinterpret_cast<uintptr_t>(qk2) |
                 reinterpret_cast<uintptr_t>(dctx) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0,
               "coattn backward (fp32 bag): operands must be 16-byte aligned");
     const dim3 grid = plan_grid(plan);
-    if (n_q <= 6)
-        coattn_bwd_f32_kernel<6><<<grid, F_WAVES * 64, 0, stream>>>(static_cast<const float*>(bag), cu, qk2, lse2, dctx, delta, ctx,
-                                                                   static_cast<float*>(dbag), part_dqk, part_colsum, n_q, plan);
-    else
-        coattn_bwd_f32_kernel<8><<<grid, F_WAVES * 64, 0, stream>>>(static_cast<const float*>(bag), cu, qk2, lse2, dctx, delta, ctx,
-                                                                   static_cast<float*>(dbag), part_dqk, part_colsum, n_q, plan);
+#define MPO_F32_BWD(NQ_, DM_) coattn_bwd_f32_kernel<NQ_, DM_><<<grid, F_WAVES * 64, 0, stream>>>(static_cast<const float*>(bag), cu, qk2, lse2, dctx, \
+        delta, ctx, da_map, static_cast<float*>(dbag), part_dqk, part_colsum, n_q, plan)
+    if (n_q <= 6) { if (da_map) MPO_F32_BWD(6, true); else MPO_F32_BWD(6, false); }
+    else          { if (da_map) MPO_F32_BWD(8, true); else MPO_F32_BWD(8, false); }
+#undef MPO_F32_BWD
     MPO_LAUNCH_CHECK();
     return 0;
 }

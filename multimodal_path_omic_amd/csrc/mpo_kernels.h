@@ -158,12 +158,12 @@ int mpo_launch_coattn_bwd(const void* bag, int bag_f32, const int* cu, int n_sli
 // the same pass for a bf16 bag at embed 256, <= 8 queries, no map gradient, two waves per SIMD (coattn_bwd8.hip);
 // mpo_launch_coattn_bwd routes to it when mpo_coattn_bwd8_covers()
 bool mpo_coattn_bwd8_covers(int bag_f32, int embed, int n_q, const float* da_map);
-// K1 backward of an fp32 bag on the vector ALUs (coattn_bwd_f32.hip): embed 256, n_q <= 8, no map gradient
+// K1 backward of an fp32 bag on the vector ALUs (coattn_bwd_f32.hip): embed 256, n_q <= 8, with or without a map gradient
 int mpo_coattn_bwd_f32_enable(int enabled);
 bool mpo_coattn_bwd_f32_covers(int bag_f32, int embed, int n_q, const float* da_map);
 int mpo_launch_coattn_bwd_f32(const void* bag, const int* cu, const float* qk2, const float* lse2, const float* dctx,
-                              const float* delta, const float* ctx, void* dbag, float* part_dqk, float* part_colsum, int n_q,
-                              const BagPlan& plan, hipStream_t stream);
+                              const float* delta, const float* ctx, const float* da_map, void* dbag, float* part_dqk,
+                              float* part_colsum, int n_q, const BagPlan& plan, hipStream_t stream);
 int mpo_coattn_bwd8_enable(int enabled);   // returns the previous setting
 int mpo_launch_coattn_bwd8(const void* bag, const int* cu, const float* qk2, const float* lse2, const float* dctx,
                            const float* delta, const float* ctx, void* dbag, float* part_dqk, float* part_colsum, int n_q,

@@ -9,8 +9,9 @@ import pytest
 
 _build = importlib.import_module("multimodal_path_omic_amd._build")
 
-# Known debt, bytes of scratch per lane allowed.  E=512 ('big' config) and the fp32-bag backward at E=256 exceed the
-# 512-register budget of one wave per SIMD; they are parity cases, not bench configurations.
+# Known debt, bytes of scratch per lane allowed.  E=512 ('big' config) and the general fp32-bag backward at E=256 exceed the
+# 512-register budget of one wave per SIMD; they are parity cases, not bench configurations -- the
+# latter is reached only by an fp32 bag with 9..16 queries (up to 8, with or without a gradient on the map: coattn_bwd_f32.hip).
 # The key projection spills 4 loop-invariant registers OUTSIDE its steady-state loop.
 ALLOWED = {
     "coattn_fwd_partial_kernelILi512ELb0": 1024,

@@ -307,3 +307,62 @@ def test_fp32_bag_vector_backward_equals_the_general_kernel_and_fp64(dev, n_q):
     for k in dwv:
         assert relerr(dwv[k], w64[k].grad) < 5e-5, k
     assert relerr(dbv, dbm) < 1e-4 and relerr(dqv, dqm) < 1e-4
+
+
+@pytest.mark.parametrize("n_q", [1, 6, 8])
+def test_fp32_bag_vector_backward_with_a_gradient_on_the_map(dev, n_q):
+    """The `cesar` loss puts a gradient on the co-attention map (models/loss.py:88-101).  For an fp32 bag the vector-ALU backward
+    takes it too (r04: the map's gradient enters on the folded registers, a step's 16 rows x 8 queries fetched as two coalesced
+    loads and broadcast along the lane rows; the general kernel -- 1 KB of scratch per lane in this geometry -- keeps 9..16
+    queries): against the general kernel and a torch fp64 restatement on a ragged window with full and ragged 16-row steps."""
+    from multimodal_path_omic_amd import _lib as L
+    from multimodal_path_omic_amd import ops
+    lengths = [1, 15, 16, 17, 33, 255, 700, 3000, 5000]
+    g = syn.rng(277 + n_q)
+    sd = syn.fill_state_dict(C.MCAT_COATTN_SHAPES, 278)
+    p = {k[len("co_attention."):]: v.to(dev) for k, v in sd.items()}
+    bags = [syn.normal(g, (m, C.E)).to(dev) for m in lengths]
+    query = syn.normal(g, (len(lengths) * n_q, C.E)).to(dev)
+    probe = syn.normal(g, (len(lengths) * n_q, C.E)).to(dev)
+    probe_map = [syn.normal(g, (n_q, m)).to(dev) for m in lengths]
+
+    def run(vector):
+        prev = L.lib().mpo_set_coattn_bwd_f32_vector(int(vector))
+        try:
+            batch = BagBatch.from_list(bags)
+            data = batch.data.detach().requires_grad_(True)
+            q = query.clone().requires_grad_(True)
+            w = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            out, amap = ops.coattn_mcat(q, batch.with_data(data), w["in_proj_weight"], w["in_proj_bias"], w["out_proj.weight"],
+                                        w["out_proj.bias"], True, 0.0)
+            maps = batch.split_map(amap, n_q)
+            loss = (out * probe).sum()
+            for a, pm in zip(maps, probe_map):
+                loss = loss + (a * pm).sum()
+            loss.backward()
+            return data.grad, q.grad, {k: v.grad for k, v in w.items()}
+        finally:
+            L.lib().mpo_set_coattn_bwd_f32_vector(prev)
+    dbv, dqv, dwv = run(True)
+    dbm, dqm, dwm = run(False)
+    e = C.E
+    w64 = {k: v.double().cpu().requires_grad_(True) for k, v in p.items()}
+    q64 = query.double().cpu().requires_grad_(True)
+    b64 = [b.double().cpu().requires_grad_(True) for b in bags]
+    wq, wk, wv = w64["in_proj_weight"][:e], w64["in_proj_weight"][e:2 * e], w64["in_proj_weight"][2 * e:]
+    bq, bk, bv = w64["in_proj_bias"][:e], w64["in_proj_bias"][e:2 * e], w64["in_proj_bias"][2 * e:]
+    loss = 0.0
+    for i, hb in enumerate(b64):
+        qq = q64[i * n_q:(i + 1) * n_q] @ wq.T + bq
+        a = torch.softmax(qq @ (hb @ wk.T + bk).T / math.sqrt(e), dim=-1)
+        o = (a @ (hb @ wv.T + bv)) @ w64["out_proj.weight"].T + w64["out_proj.bias"]
+        loss = loss + (o * probe[i * n_q:(i + 1) * n_q].double().cpu()).sum() + (a * probe_map[i].double().cpu()).sum()
+    loss.backward()
+    db64 = torch.cat([b.grad for b in b64])
+    ev, em = relerr(dbv, db64), relerr(dbm, db64)
+    print(f"[K1 fp32 backward, map gradient] n_q={n_q}: d_bag vs fp64: vector {ev:.2e}, matrix pipe {em:.2e}; query {relerr(dqv, q64.grad):.2e}")
+    assert ev < 2e-5 and ev <= em * 1.5 + 1e-6, (ev, em)
+    assert relerr(dqv, q64.grad) < 2e-5
+    for k in dwv:
+        assert relerr(dwv[k], w64[k].grad) < 5e-5, k
+    assert relerr(dbv, dbm) < 1e-4 and relerr(dqv, dqm) < 1e-4
