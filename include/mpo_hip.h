@@ -207,7 +207,7 @@ int mpo_set_gemm_fast_path(int enabled);
  * enabled = 0 sends every geometry through the general kernel.  Returns the previous setting (default 1).  ABI v11. */
 int mpo_set_coattn_bwd_two_wave(int enabled);
 
-/* K1 backward of an fp32-stored bag (embed 256, n_q <= 8, no map gradient) runs on the vector ALUs in plain fp32
+/* K1 backward of an fp32-stored bag (embed 256, n_q <= 8, with or without a map gradient) runs on the vector ALUs in plain fp32
  * (csrc/coattn_bwd_f32.hip: with six queries every product is skinny; the matrix-pipe kernel needs split images, both
  * orientations and 1 KB of scratch per lane for the same result).  enabled = 0 sends fp32 bags through the general kernel as
  * the check of this one.  Returns the previous setting (default 1).  ABI v12. */
