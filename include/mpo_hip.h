@@ -273,7 +273,9 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                 float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
-                                float* d_query, void* d_kbag, int dk_dtype, float* d_kbag_colsum /* nullable [embed] */,
+                                float* d_query, int d_query_accumulate /* ABI v14: d_query += (it already holds the gradient
+                                                of the query's other consumers) */,
+                                void* d_kbag, int dk_dtype, float* d_kbag_colsum /* nullable [embed] */,
                                 void* d_hbag /* nullable when d_ctx is given */,
                                 float* d_ctx /* nullable [n_slides*n_q][embed]: receives dL/d(A_drop V-side context); the
                                                 dH outer product is then left to mpo_nacagat_patch_grad() */,
@@ -421,10 +423,13 @@ int mpo_fusion_head_loss_backward(const float* hcat, int n_slides, int din, int 
  * fc_c.0.weight,.bias */
 size_t mpo_cag_saved_floats(int rows, int hidden);
 size_t mpo_cag_workspace_bytes(int rows, int hidden);
+/* ABI v14: residual / sum_out (both or neither): sum_out = residual + C in the forward's last launch -- the caller's
+ * attn_output + CAG(query, q_proj) of models/blocks.py:110 without an element-wise pass; d_q_accumulate: d_q += . */
 int mpo_cag_forward(const float* q, const float* q_hat, int rows, int dim, int hidden, const float* const* params,
-                    float* c_out, float* saved, mpo_stream_t stream);
+                    float* c_out, float* saved, const float* residual /* nullable [rows, hidden] */,
+                    float* sum_out /* nullable [rows, hidden] */, mpo_stream_t stream);
 int mpo_cag_backward(const float* q, const float* q_hat, int rows, int dim, int hidden, const float* const* params,
-                     const float* saved, const float* c_out, const float* d_c, float* d_q, float* d_q_hat,
+                     const float* saved, const float* c_out, const float* d_c, float* d_q, int d_q_accumulate, float* d_q_hat,
                      float* const* grads, void* workspace, size_t workspace_bytes, mpo_stream_t stream);
 
 /* ---- omic SNNs self.G (models/mcat/mcat.py:32-45,90-92): per group Linear+ELU+AlphaDropout twice, all groups

@@ -71,7 +71,7 @@ _SIGNATURES = {
                                            c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_coattn_nacagat_backward": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P,
                                             c_float, c_uint64, c_uint64, _P, _P, _P, _P, _P, _P, _P,
-                                            _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                            _P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mpo_nacagat_patch_grad": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_size_t, _P]),
     "mpo_nacagat_patch_grad_fused": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
                                              c_size_t, _P]),
@@ -114,8 +114,8 @@ _SIGNATURES = {
                                       _P, c_size_t, _P]),
     "mpo_cag_saved_floats": (c_size_t, [c_int] * 2),
     "mpo_cag_workspace_bytes": (c_size_t, [c_int] * 2),
-    "mpo_cag_forward": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
-    "mpo_cag_backward": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "mpo_cag_forward": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "mpo_cag_backward": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_size_t, _P]),
 }
 
 

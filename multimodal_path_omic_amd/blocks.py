@@ -149,14 +149,23 @@ class PreGatingContextualAttention(nn.Module):
         nn.init.zeros_(self.in_proj_bias)
         nn.init.zeros_(self.out_proj.bias)
 
-    def forward_window(self, query: torch.Tensor, bags: BagBatch, bag_relu_gate: float = 0.0):
+    def forward_window(self, query: torch.Tensor, bags: BagBatch, bag_relu_gate: float = 0.0, pair=None):
+        """pair (ops.TokenPair): attn_out + CAG is produced into pair.slot(0) by CAG's last launch and the query is handed
+        through both ops, so the window step has no element-wise add, no stack copy and no gradient adds for the three
+        uses of the omic tokens; a third result is then the query to give to the omic branch."""
         n_slides, n_q, e = query.shape
         q2 = query.reshape(n_slides * n_q, e)
-        q_proj, out, amap = ops.coattn_nacagat(q2, bags, self.in_proj_weight, self.in_proj_bias,
-                                               self.out_proj.weight, self.out_proj.bias,
-                                               self.dropout if self.training else 0.0, bag_relu_gate)
-        c = self.CAG(q2, q_proj)
-        return (out + c).view(n_slides, n_q, e), bags.split_map(amap, n_q)
+        drop = self.dropout if self.training else 0.0
+        if pair is None:
+            q_proj, out, amap = ops.coattn_nacagat(q2, bags, self.in_proj_weight, self.in_proj_bias,
+                                                   self.out_proj.weight, self.out_proj.bias, drop, bag_relu_gate)
+            total = ops.contextual_gate(q2, q_proj, self.CAG, residual=out)
+            return total.view(n_slides, n_q, e), bags.split_map(amap, n_q)
+        q_proj, out, amap, q_on = ops.coattn_nacagat(q2, bags, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight,
+                                                     self.out_proj.bias, drop, bag_relu_gate, hand_on=True)
+        total, q_on = ops.contextual_gate(q_on, q_proj, self.CAG, residual=out, dest=(pair, 0),
+                                          hand_on=True)
+        return total.view(n_slides, n_q, e), bags.split_map(amap, n_q), q_on.view(n_slides, n_q, e)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, **unused):
         bag = _as_bag(key, value)

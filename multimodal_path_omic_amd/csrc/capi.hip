@@ -83,7 +83,7 @@ static size_t max_parts(int n_slides) { return (size_t)mpo_coattn_target_workgro
 
 extern "C" {
 
-int mpo_abi_version(void) { return 13; }
+int mpo_abi_version(void) { return 14; }
 const char* mpo_last_error(void) { return g_err; }
 
 int mpo_linear_forward(const float* x, const float* weight, const float* bias, float* y, int rows, int in_features,
@@ -453,8 +453,8 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
                                 const float* out_w, float drop_p, uint64_t seed, uint64_t offset, const uint64_t* rng_epoch,
                                 const float* saved, const float* score_maps, const float* attn_map,
                                 const float* d_out, const float* d_attn_map, const float* d_q_proj,
-                                float* d_query, void* d_kbag, int dk_dtype, float* d_kbag_colsum, void* d_hbag, float* d_ctx,
-                                float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
+                                float* d_query, int d_query_accumulate, void* d_kbag, int dk_dtype, float* d_kbag_colsum, void* d_hbag,
+                                float* d_ctx, float* d_in_w, float* d_in_b, float* d_out_w, float* d_out_b,
                                 const mpo_bag_plan* plan_, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     if (int rc = check_common(bag_dtype, n_slides, total_rows, max_rows, n_q, embed)) return rc;
     MPO_CHECK(k_dtype == MPO_F32, "nacagat co-attention: K must be fp32 (k_dtype %d): the narrow gate amplifies key rounding", k_dtype);
@@ -546,7 +546,7 @@ int mpo_coattn_nacagat_backward(const void* kbag, int k_dtype, const void* hbag,
     }
     auto query_side = [&]() -> int {
         if (int r = mpo_launch_qprep_bwd(dqt, dtq, tq, d_q_proj, dq, R * E, 1.0f / sqrtf((float)E), stream)) return r;
-        return mpo_linear_bwd_pair(mpo_args_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, 0),
+        return mpo_linear_bwd_pair(mpo_args_bwd_input(dq, w_q, d_query, R, E, E, 1.0f, d_query_accumulate ? 1 : 0),
                                    mpo_args_bwd_weight(dq, query, d_in_w, d_in_b, R, E, E, 1.0f), stream);
     };
     if (!one_pass)

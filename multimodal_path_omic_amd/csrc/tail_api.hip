@@ -587,7 +587,8 @@ size_t mpo_cag_workspace_bytes(int rows, int hidden) {
 
 // ContextualAttentionGate.forward, models/blocks.py:247-253
 int mpo_cag_forward(const float* q, const float* q_hat, int rows, int dim, int hidden, const float* const* P,
-                    float* c_out, float* saved, mpo_stream_t stream) {
+                    float* c_out, float* saved, const float* residual, float* sum_out, mpo_stream_t stream) {
+    MPO_CHECK((residual == nullptr) == (sum_out == nullptr), "CAG forward: residual and sum_out go together");
     Carver c(saved);
     float* u1 = c.take((size_t)rows * hidden); float* u2 = c.take((size_t)rows * hidden); float* u3 = c.take((size_t)rows * hidden);
     float* t1 = c.take((size_t)rows * hidden); float* t3 = c.take((size_t)rows * hidden);
@@ -599,12 +600,19 @@ int mpo_cag_forward(const float* q, const float* q_hat, int rows, int dim, int h
                              mpo_args_fwd(q_hat, P[2], P[3], u2, rows, dim, hidden, 1.0f, MPO_ACT_ELU), &g3));
     }
     RC(mpo_launch_cag_mid_fwd(u1, u2, u3, P[6], P[7], P[8], P[9], t1, t3, g, e, m, sg, se, rows, hidden, 1e-5f, stream));
-    RC(mpo_linear_fwd(m, P[10], P[11], c_out, rows, hidden, hidden, 1.0f, MPO_ACT_ELU, stream));
+    if (sum_out == nullptr) {
+        RC(mpo_linear_fwd(m, P[10], P[11], c_out, rows, hidden, hidden, 1.0f, MPO_ACT_ELU, stream));
+    } else {
+        // the caller's  residual + C  (models/blocks.py:110: attn_output + CAG(...)) rides in the same launch as a second member
+        // of the same product: C alone stays in c_out (its ELU derivative is read off it in the backward)
+        RC(mpo_gemm_together(stream, mpo_args_fwd(m, P[10], P[11], c_out, rows, hidden, hidden, 1.0f, MPO_ACT_ELU),
+                             mpo_args_fwd(m, P[10], P[11], sum_out, rows, hidden, hidden, 1.0f, MPO_ACT_ELU, residual)));
+    }
     return 0;
 }
 
 int mpo_cag_backward(const float* q, const float* q_hat, int rows, int dim, int hidden, const float* const* P,
-                     const float* saved, const float* c_out, const float* d_c, float* d_q, float* d_q_hat,
+                     const float* saved, const float* c_out, const float* d_c, float* d_q, int d_q_accumulate, float* d_q_hat,
                      float* const* G, void* workspace, size_t workspace_bytes, mpo_stream_t stream) {
     Carver c(const_cast<float*>(saved));
     const float* u1 = c.take((size_t)rows * hidden); const float* u2 = c.take((size_t)rows * hidden);
@@ -626,7 +634,7 @@ int mpo_cag_backward(const float* q, const float* q_hat, int rows, int dim, int 
     // u1 = ELU(fc1 q), u2 = ELU(fc2 qh), u3 = ELU(fc3 qh)
     {   // five independent products in one mixed launch; d_q_hat accumulates its second product afterwards
         GemmGroup grp;
-        grp.g[0] = mpo_args_bwd_input(ds12, P[0], d_q, rows, dim, hidden, 1.0f, 0, gate(u1, MPO_GATE_ELU));
+        grp.g[0] = mpo_args_bwd_input(ds12, P[0], d_q, rows, dim, hidden, 1.0f, d_q_accumulate ? 1 : 0, gate(u1, MPO_GATE_ELU));
         grp.g[1] = mpo_args_bwd_weight(ds12, q, G[0], G[1], rows, dim, hidden, 1.0f, gate(u1, MPO_GATE_ELU));
         grp.g[2] = mpo_args_bwd_input(ds12, P[2], d_q_hat, rows, dim, hidden, 1.0f, 0, gate(u2, MPO_GATE_ELU));
         grp.g[3] = mpo_args_bwd_weight(ds12, q_hat, G[2], G[3], rows, dim, hidden, 1.0f, gate(u2, MPO_GATE_ELU));

@@ -203,11 +203,24 @@ class NarrowContextualAttentionGateTransformer(_FusionModelBase):
         #  runs the column-half passes of csrc/capi.hip and leaves that derivative to the patch layer's own backward)
         return self.model_sizes[1] != 512
 
-    def _co_attend(self, g_bag, h_bags, inference):
-        gate = 0.0
+    def _bag_gate(self, h_bags):
         if h_bags.data.dtype == torch.bfloat16 and self._fused_bag_gate:
-            gate = getattr(h_bags.data, "_mpo_keep_scale", 1.0 / (1.0 - self.H[2].p)) if self.training else 1.0
-        return self.co_attention.forward_window(g_bag, h_bags, bag_relu_gate=gate)
+            return getattr(h_bags.data, "_mpo_keep_scale", 1.0 / (1.0 - self.H[2].p)) if self.training else 1.0
+        return 0.0
+
+    def _co_attend(self, g_bag, h_bags, inference):
+        return self.co_attention.forward_window(g_bag, h_bags, bag_relu_gate=self._bag_gate(h_bags))
+
+    def _token_pair(self, bags: BagBatch, omics):
+        """attn_out + CAG and the omic tokens are produced straight into the (2, B, N, d) buffer the branch-batched encoder reads
+        (no element-wise add, no torch.stack copy, no gradient adds for the three consumers of G_bag)."""
+        return ops.TokenPair(bags.n_slides * len(omics), self.H[0].out_features, bags.data.device)
+
+    def _patch_and_co_attend(self, g_bag, bags: BagBatch, inference: bool, pair=None):
+        if pair is None:
+            return super()._patch_and_co_attend(g_bag, bags, inference)
+        h_bags = self._patch_fc(bags)
+        return self.co_attention.forward_window(g_bag, h_bags, bag_relu_gate=self._bag_gate(h_bags), pair=pair)
 
     def forward(self, wsi, omics):
         return self._forward_one(wsi, omics, True)

@@ -614,43 +614,61 @@ def gated_scores(x, wa, ba, wb, bb, wc, bc, drop_p: float):
 
 
 class CagFn(torch.autograd.Function):
-    """K3: ContextualAttentionGate (models/blocks.py:247-253), one C-ABI call each way."""
+    """K3: ContextualAttentionGate (models/blocks.py:247-253), one C-ABI call each way.
+    residual / dest: the caller's  residual + C  (models/blocks.py:110) is produced into `dest` by the forward's last launch (no
+    element-wise pass).  The second output hands q on to its other consumers: their gradient then arrives HERE and the
+    backward's d_q product accumulates onto it (no gradient-add launch)."""
 
     @staticmethod
-    def forward(ctx, q, q_hat, *params):
+    def forward(ctx, q, q_hat, residual, dest, *params):
         lib = L.lib()
+        ctx.set_materialize_grads(False)
         q, q_hat = q.contiguous(), q_hat.contiguous()
         rows, dim = q.shape
         hidden = params[0].shape[0]
         c = torch.empty(rows, hidden, device=q.device, dtype=torch.float32)
         saved = torch.empty(lib.mpo_cag_saved_floats(rows, hidden), device=q.device, dtype=torch.float32)
         pa = L.ptr_array(params)
-        L.check(lib.mpo_cag_forward(L.ptr(q), L.ptr(q_hat), rows, dim, hidden, pa, L.ptr(c), L.ptr(saved),
-                                    L.stream_of(q)), "mpo_cag_forward")
+        total = None
+        if residual is not None:
+            residual = residual.contiguous()
+            # dest = (TokenPair, slot): a non-tensor argument -- the slot's view is created here, so autograd sees a fresh output
+            total = dest[0].slot(dest[1], (rows, hidden)) if dest is not None else torch.empty_like(c)
+        L.check(lib.mpo_cag_forward(L.ptr(q), L.ptr(q_hat), rows, dim, hidden, pa, L.ptr(c), L.ptr(saved), L.ptr(residual),
+                                    L.ptr(total), L.stream_of(q)), "mpo_cag_forward")
         ctx.save_for_backward(q, q_hat, c, saved, *params)
         ctx.param_refs = params
-        return c
+        ctx.has_residual = residual is not None
+        return (total if total is not None else c), q.view_as(q)
 
     @staticmethod
-    def backward(ctx, dc):
+    def backward(ctx, dc, d_qpass):
         lib = L.lib()
         q, q_hat, c, saved, *params = ctx.saved_tensors
         rows, dim = q.shape
         hidden = params[0].shape[0]
-        dq, dqh = torch.empty_like(q), torch.empty_like(q_hat)
+        if dc is None:
+            dc = torch.zeros_like(c)
+        dc = dc.contiguous()
+        accumulate = d_qpass is not None
+        dq = d_qpass.contiguous() if accumulate else torch.empty_like(q)      # (in place on the incoming gradient)
+        dqh = torch.empty_like(q_hat)
         grads = [grad_out(p) for p in ctx.param_refs]
         ws = _workspace(lib.mpo_cag_workspace_bytes(rows, hidden), q.device)
         pa, ga = L.ptr_array(params), L.ptr_array(grads)
         L.check(lib.mpo_cag_backward(L.ptr(q), L.ptr(q_hat), rows, dim, hidden, pa, L.ptr(saved), L.ptr(c),
-                                     L.ptr(dc.contiguous()), L.ptr(dq), L.ptr(dqh), ga, L.ptr(ws), ws.numel(),
+                                     L.ptr(dc), L.ptr(dq), int(accumulate), L.ptr(dqh), ga, L.ptr(ws), ws.numel(),
                                      L.stream_of(q)), "mpo_cag_backward")
-        return (dq, dqh, *grads)
+        return (dq, dqh, dc if ctx.has_residual else None, None, *grads)
 
 
-def contextual_gate(q, q_hat, cag):
-    return CagFn.apply(q, q_hat, cag.fc1[0].weight, cag.fc1[0].bias, cag.fc2[0].weight, cag.fc2[0].bias,
-                       cag.fc3[0].weight, cag.fc3[0].bias, cag.G[1].weight, cag.G[1].bias,
-                       cag.E[1].weight, cag.E[1].bias, cag.fc_c[0].weight, cag.fc_c[0].bias)
+def contextual_gate(q, q_hat, cag, residual=None, dest=None, hand_on: bool = False):
+    """C = CAG(q, q_hat); with `residual`: residual + C (into slot dest[1] of the TokenPair dest[0] when given).  hand_on: also returns q for its other
+    consumers (use THAT tensor there: their gradient is then folded into this op's backward)."""
+    out, q_pass = CagFn.apply(q, q_hat, residual, dest, cag.fc1[0].weight, cag.fc1[0].bias, cag.fc2[0].weight, cag.fc2[0].bias,
+                              cag.fc3[0].weight, cag.fc3[0].bias, cag.G[1].weight, cag.G[1].bias,
+                              cag.E[1].weight, cag.E[1].bias, cag.fc_c[0].weight, cag.fc_c[0].bias)
+    return (out, q_pass) if hand_on else out
 
 
 class EncoderFn(torch.autograd.Function):
@@ -1210,10 +1228,12 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         ctx.hb = hb if big else None                  # (the split-halves copy of the bag: kept for the backward)
         ctx.param_refs = (in_w, in_b, out_w, out_b)
         ctx.batch, ctx.n_q, ctx.drop = batch, n_q, (float(drop_p), seed, offset)
-        return q_proj, out, amap
+        # (4th output: the query handed on to its other consumers -- NaCAGaT's CAG and the omic branch's tokens; their gradient
+        #  arrives here and the backward's d_query product accumulates onto it)
+        return q_proj, out, amap, query.view_as(query)
 
     @staticmethod
-    def backward(ctx, d_qproj, d_out, d_map):
+    def backward(ctx, d_qproj, d_out, d_map, d_qpass=None):
         lib = L.lib()
         query, bag_data, kbag, in_w, in_b, out_w, saved, score_maps, amap = ctx.saved_tensors
         batch, n_q = ctx.batch, ctx.n_q
@@ -1223,7 +1243,8 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         d_out = d_out.contiguous() if d_out is not None else torch.zeros(R, E, device=dev)
         d_qproj = d_qproj.contiguous() if d_qproj is not None else None
         d_map = d_map.contiguous() if d_map is not None else None
-        d_query = torch.empty_like(query)
+        accumulate = d_qpass is not None
+        d_query = d_qpass.contiguous() if accumulate else torch.empty_like(query)      # (in place on the incoming gradient)
         d_k = torch.empty_like(kbag, dtype=bag_data.dtype)       # a bf16 bag takes its key gradient in bf16 (see below)
         # bf16 bag: the patch-side gradient is finished by ONE pass after the dK W_k GEMM (mpo_nacagat_patch_grad) instead
         # of outer-product kernel -> addmm_ read-modify-write -> element-wise derivative pass
@@ -1238,7 +1259,7 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
             L.ptr(kbag), L.MPO_F32, L.ptr(hb), L.bag_dtype_code(bag_data), L.ptr(batch.cu), batch.n_slides, T,
             batch.max_rows, L.ptr(query), n_q, E, L.ptr(in_w), L.ptr(in_b), L.ptr(out_w), drop_p, seed, offset,
             _epoch(), L.ptr(saved), L.ptr(score_maps), L.ptr(amap), L.ptr(d_out), L.ptr(d_map), L.ptr(d_qproj),
-            L.ptr(d_query), L.ptr(d_k), L.bag_dtype_code(d_k), L.ptr(d_in_b[E:2 * E]), L.ptr(d_h), L.ptr(d_ctx), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
+            L.ptr(d_query), int(accumulate), L.ptr(d_k), L.bag_dtype_code(d_k), L.ptr(d_in_b[E:2 * E]), L.ptr(d_h), L.ptr(d_ctx), L.ptr(d_in_w), L.ptr(d_in_b), L.ptr(d_out_w),
             L.ptr(d_out_b), batch.plan(), L.ptr(ws), ws.numel(), L.stream_of(query)), "mpo_coattn_nacagat_backward")
         # back through the caller-side GEMM  K = H W_k^T + b_k.  The forward K stays fp32 (the gate amplifies its
         # rounding); its GRADIENT goes through bf16 operands with fp32 accumulation for a bf16 bag: dW_k as a
@@ -1286,8 +1307,10 @@ class CoAttnNaCAGaTFn(torch.autograd.Function):
         return d_query, d_h, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None
 
 
-def coattn_nacagat(query, batch: BagBatch, in_w, in_b, out_w, out_b, drop_p: float, bag_relu_gate: float = 0.0):
-    """query (n_slides*n_q, E) -> (q_proj, attn_out (n_slides*n_q, E), ragged post-dropout map).
+def coattn_nacagat(query, batch: BagBatch, in_w, in_b, out_w, out_b, drop_p: float, bag_relu_gate: float = 0.0,
+                   hand_on: bool = False):
+    """query (n_slides*n_q, E) -> (q_proj, attn_out (n_slides*n_q, E), ragged post-dropout map[, query handed on]).
     bag_relu_gate = 1/(1-p) when the bag comes from patch_fc(..., pre_gated_grad=True): d_bag then already carries
-    that layer's ReLU/dropout derivative (bf16 bags only)."""
-    return CoAttnNaCAGaTFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, drop_p, bag_relu_gate)
+    that layer's ReLU/dropout derivative (bf16 bags only).  hand_on: a 4th result, the query for its other consumers."""
+    res = CoAttnNaCAGaTFn.apply(query, batch.data, in_w, in_b, out_w, out_b, batch, drop_p, bag_relu_gate)
+    return res if hand_on else res[:3]

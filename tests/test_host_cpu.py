@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f"{name} declared in include/mpo_hip.h but not exported"
     for name in L.exported_symbols():
         assert name in decl, f"{name} bound in _lib.py but not declared in the public header"
-    assert L.lib().mpo_abi_version() == 13
+    assert L.lib().mpo_abi_version() == 14
     # size queries are pure host functions
     assert L.lib().mpo_coattn_saved_floats(2, 6, 256) == 4 * 12 * 256 + 12
     assert L.lib().mpo_coattn_splits(32, 15000) == 8 and L.lib().mpo_coattn_splits(1, 100) == 1   # one workgroup per CU
