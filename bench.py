@@ -412,6 +412,18 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
     # state or for the first touch of the second resident window (the timed region of the driver's K = 20 is 22 ms long: one
     # 5 ms hiccup is a quarter of it -- seen once in round 3, 1.37 ms per step with every kernel at its usual time under
     # rocprofv3 minutes later).  Then the contract: W untimed warmup steps, exactly K timed ones.
+    bare_ms = None
+    if world == 1 and a.settle > 0:
+        # the bare contract first, for the record (config.ms_per_step_without_setup_replays): W warmup steps and K timed ones
+        # straight after graph capture, beside the headline figure below
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        torch.cuda.synchronize(dev)
+        bare_ms = (time.perf_counter() - t0) / steps * 1e3
     for i in range(a.settle):
         step(i)
     torch.cuda.synchronize(dev)
@@ -444,7 +456,8 @@ def run_config(a, dev, rank, world, steps, warmup, with_roofline=True):
                        "global_slides_per_step": world * a.window,
                        "patches_per_slide": "uniform[2000,30000] (fixed multiset)" if a.ragged else a.patches,
                        "parallelism": f"dp{world}", "resident_windows": a.n_windows, "launch": graph_note,
-                       "setup_replays_before_warmup": a.settle},
+                       "setup_replays_before_warmup": a.settle,
+                       "ms_per_step_without_setup_replays": None if bare_ms is None else round(bare_ms, 3)},
         }
     if rank == 0 and with_roofline:
         # the roofline kernel is timed inside the workload it belongs to: a replay of the captured step before every
