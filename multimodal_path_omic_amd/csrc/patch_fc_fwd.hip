@@ -54,7 +54,11 @@ constexpr int PERIOD = NK + EPI;                // 40
 constexpr int SKEW = 20;                        // the second stream's delay: 2 SKEW = EPI (mod 32), see the rotation rule above
 constexpr int X_IMG = CH * 2 * BK * 2;          // 16 KiB: [128 rows][128 B] = TWO k-steps (whole 128-byte lines of X)
 constexpr int W_IMG = PE * BK * 2;              // 16 KiB: [cq 4][dt 4][lane 64][16 B]
+#ifdef MPO_PF_W4
+constexpr int XSLOTS = 3, WSLOTS = 4;           // X: the pair being read + two pairs (four stages) in flight per stream; W_H: THREE stages in flight (160 KiB)
+#else
 constexpr int XSLOTS = 3, WSLOTS = 3;           // X: the pair being read + two pairs (four stages) in flight per stream; W_H: two stages in flight
+#endif
 constexpr int WAHEAD = WSLOTS - 1;
 constexpr int OFF_X = 0;                        // stream s: OFF_X + s * XSLOTS * X_IMG
 constexpr int OFF_W = 2 * XSLOTS * X_IMG;       // 96 KiB
@@ -74,7 +78,16 @@ constexpr int x_ops(int p) { return (pmod(p) % 2 == 0 && (pmod(p) <= NK - 6 || p
 constexpr int s_ops(int p) { return pmod(p) >= NK ? 2 : 0; }
 // instructions younger than this wave's W_H pieces of the stage it is about to read (requested first thing two stages before):
 // the rest of that stage, and everything of the stage in between.  (The X pair of the moment was requested earlier still.)
-constexpr int n_younger(int p) { return x_ops(p - 2) + s_ops(p - 2) + 2 + x_ops(p - 1) + s_ops(p - 1); }
+constexpr int n_younger(int p) {
+    int n = 0;
+    for (int d = 1; d <= WAHEAD; ++d) n += x_ops(p - d) + s_ops(p - d) + (d < WAHEAD ? 2 : 0);
+    return n;
+}
+// the same where there is no epilogue behind the stream yet (its first chunk) and in stages without work of its own: only what
+// is certain to be younger -- the W_H requests of the stages in between (waiting for more than necessary is safe, for less is not)
+constexpr int N_W_ONLY = 2 * (WAHEAD - 1);
+// first chunk, positions 1 and 2: the W_H requests in between and the X pair requested at position 0
+constexpr int N_FIRST_1 = WAHEAD == 2 ? 6 : 8, N_FIRST_2 = WAHEAD == 2 ? 6 : 8;
 
 __device__ __forceinline__ unsigned lds_addr(const char* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
@@ -90,12 +103,8 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // wait until at most N of this wave's vector-memory operations are outstanding
 template <int N>
 __device__ __forceinline__ void wait_vm() {
-    static_assert(N == 2 || N == 4 || N == 6 || N == 8 || N == 10, "see n_younger()");
-    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(N >= 2 && N <= 20 && N % 2 == 0, "see n_younger()");      // (the counter holds 63)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 __device__ __forceinline__ int wrap_inc(int v, int n) { return v + 1 == n ? 0 : v + 1; }
 // The 16 mask bytes of one (row, 16-column group) of the patch layer's dropout: a counter hash like hash4x32 (mpo_common.h)
@@ -306,9 +315,9 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
         issue_x(0, 1, 1);
         xw = 2;
     }
-    issue_w(0, 0);
-    issue_w(1, 1);
-    int ww = 2, wr = 0;                                           // W_H ring: slot requested next / read next
+#pragma unroll
+    for (int i = 0; i < WAHEAD; ++i) issue_w(i, i);
+    int ww = WAHEAD % WSLOTS, wr = 0;                             // W_H ring: slot requested next / read next
     // Every wave goes through the same G stages (one workgroup barrier each); what it does between the barrier and its requests
     // depends on where its stream is.  pre<N>(): the stage has landed.  Own pieces: gfx950 retires a wave's vector-memory
     // operations in issue order, N = the number of this wave's operations younger than its W_H pieces of this stage (static:
@@ -353,12 +362,12 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
     using T = integral_constant<bool, true>;
     using F = integral_constant<bool, false>;
 #define MPO_N(p) integral_constant<int, n_younger(p)>{}
-    using N2 = integral_constant<int, 2>;
-    using N4 = integral_constant<int, 4>;
-    using N6 = integral_constant<int, 6>;
+    using NW = integral_constant<int, N_W_ONLY>;
+    using NF1 = integral_constant<int, N_FIRST_1>;
+    using NF2 = integral_constant<int, N_FIRST_2>;
 
     for (int i = 0; i < st * SKEW && gs < G; ++i) {               // the lagging stream's head start for the other one
-        pre(N2{});
+        pre(NW{});
         MPO_KIND(3)
         req_w();
         adv();
@@ -366,20 +375,22 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
     for (int cj = 0; cj < n_mine; ++cj) {
         bf16x8 pw[4], qw[4], fx[8];
         // position 0: reads only
-        if (cj == 0) pre(N2{}); else pre(MPO_N(0));               // (first chunk: nothing but W_H stage + 1 is younger)
+        if (cj == 0) pre(NW{}); else pre(MPO_N(0));               // (first chunk: nothing but the W_H stages in between is younger)
         MPO_KIND(2)
         req_w();
         req_x(cj, 2);
         stage(T{}, F{}, F{}, xr, 0, wr, pw, qw, fx);
         adv();
-        static_assert(n_younger(2) == 6 && n_younger(3) == 6 && n_younger(27) == 6 && n_younger(28) == 6, "main loop counts");
-        if (cj == 0) pre(N6{}); else pre(MPO_N(1));               // (first chunk: no epilogue stores before it)
+        static_assert(n_younger(3) == n_younger(5) && n_younger(3) == n_younger(25) && n_younger(4) == n_younger(6) &&
+                      n_younger(4) == n_younger(26), "main loop counts");
+        static_assert(WAHEAD == 2 ? n_younger(2) == N_FIRST_2 : n_younger(2) == N_FIRST_2 + 2, "position 2: the epilogue's last stores are in the window at three ahead");
+        if (cj == 0) pre(NF1{}); else pre(MPO_N(1));              // (first chunk: no epilogue stores before it)
         MPO_KIND(0)
         req_w();
         stage(F{}, F{}, T{}, xr, 1, wr, qw, pw, fx);              // position 1: the chunk's first MFMAs (accumulators start from zero)
         xr = wrap_inc(xr, XSLOTS);
         adv();
-        pre(MPO_N(2));
+        if (cj == 0) pre(NF2{}); else pre(MPO_N(2));
         req_w();
         req_x(cj, 3);
         stage(F{}, F{}, F{}, xr, 0, wr, pw, qw, fx);
@@ -390,7 +401,7 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
             stage(F{}, F{}, F{}, xr, 1, wr, qw, pw, fx);
             xr = wrap_inc(xr, XSLOTS);
             adv();
-            pre(MPO_N(2));
+            pre(MPO_N(4));
             req_w();
             req_x(cj, q + 3);
             stage(F{}, F{}, F{}, xr, 0, wr, pw, qw, fx);
@@ -427,13 +438,13 @@ void patch_fc_fwd_kernel(const __bf16* __restrict__ x,            // [total_rows
         req_w();
         adv();
         if (gs < G) {
-            pre(N4{});                                            // (.. "41": the last epilogue stage's stores and the W_H request of "40")
+            pre(integral_constant<int, 4>{});                     // (.. "41": at least the last epilogue stage's stores and the W_H request of "40")
             req_w();
             adv();
         }
     }
     while (gs < G) {
-        pre(N2{});
+        pre(NW{});
         req_w();
         adv();
     }
