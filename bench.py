@@ -130,10 +130,12 @@ def _time_launches(dev, launch, reps, burst=4, between=None):
     between is None: one event pair brackets a burst of back-to-back launches (alternating resident inputs): a pair around
       a single launch also times that launch's dispatch latency (~3 us, which rocprofv3's kernel duration does not
       contain); inside a burst the next dispatch overlaps the running kernel.
-    between given: every timed launch is preceded by between(i) -- one replay of the captured window step -- so the kernel
-      is timed in the state the chip has when it runs inside the workload.  Back-to-back launches of a kernel that mixes
-      250 GF of MFMA work with a 1.2 GB stream hold the chip in a lower clock state than the step does (DESIGN.md section 3,
-      dW_H): the burst figure of such a kernel is ~15 % worse than what the same kernel takes inside the step.
+    between given: every event pair is preceded by between(i) -- one replay of the captured window step -- so the kernel
+      is timed in the state the chip has when it runs inside the workload, and brackets TWO launches (on the two resident
+      inputs).  A pair around ONE launch right behind the step reads 10-20 us high with a wide spread (r04,
+      tools/gpu_probe_event_timing.py: 288 us average / 270 minimum for the patch-layer kernel, against 276 / 273 per launch
+      with two launches per pair, 274 / 270 with four, and 257-262 us for the same kernel in rocprofv3's timeline of the
+      step); long bursts of the r03 kernel had read ~15 % slow instead (lower clock state), hence two.
     Returns (sorted per-launch microseconds, launches per event pair)."""
     import torch
     stream = torch.cuda.current_stream(dev)
@@ -142,7 +144,7 @@ def _time_launches(dev, launch, reps, burst=4, between=None):
     torch.cuda.synchronize(dev)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     if between is not None:
-        burst = 1
+        burst = 2
     for i, (s, e) in enumerate(evs):
         if between is not None:
             between(i)
@@ -230,7 +232,7 @@ def roofline_leg(dev, window, patches, bag_dtype, kind="mcat", reps=20, between=
         alg_bytes = window * patches * E * esz
         name = "bag_rowdot_gated_exact_kernel<256> (f32 key bag)" if k2 else "coattn_fwd_partial_kernel<256,%s>" % ("bf16" if esz == 2 else "f32")
         applies = (window == 32 and patches == 15000) or (window == 8 and patches == 100000 and esz == 4 and not k2)
-    extra = {"timing": "each launch preceded by one replay of the window step"} if between is not None else {}
+    extra = {"timing": "each event pair brackets two launches (the two resident inputs) and is preceded by one replay of the window step"} if between is not None else {}
     us, burst = _time_launches(dev, launch, reps, between=between)
     avg_us = sum(us) / len(us)
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
